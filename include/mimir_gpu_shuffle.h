@@ -1,0 +1,194 @@
+/*
+ * mimir_gpu_shuffle.h -- C ABI of the MI355X (gfx950) map-side shuffle
+ * transform: hash every <key,value> record with lookup3 hashlittle, take
+ * `hash % nranks` as its destination, and pack the records, in stable emit
+ * order, into per-destination partitions of a send image.
+ *
+ * The library stands in for the per-record work of Mimir's
+ * CollectiveShuffler / NBCollectiveShuffler.  Every entry point names the
+ * reference code (paths relative to a Mimir checkout) whose behaviour it
+ * reproduces bit for bit.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; pointers prefixed d_ are DEVICE pointers
+ *     on the handle's HIP device, everything else is host memory;
+ *   - every function returns 0 (MGS_OK) or a negative mgs_status, and leaves
+ *     a human-readable message retrievable with mgs_last_error();
+ *   - a handle is bound to one HIP device and must be driven by one host
+ *     thread at a time (the reference is single-threaded per rank,
+ *     examples/wordcount.cpp:33);
+ *   - records travel in WIRE FORM: the bytes Serializer::kv_to_bytes writes
+ *     for one pair -- key bytes immediately followed by value bytes, no
+ *     header, no padding (src/serializer.h:348-364).  A char* key is its
+ *     characters plus the terminating NUL (src/serializer.h:145-157).
+ */
+#ifndef MIMIR_GPU_SHUFFLE_H
+#define MIMIR_GPU_SHUFFLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGS_MAX_RANKS 256 /* destinations per handle (dest ids are one byte) */
+
+typedef enum mgs_status {
+    MGS_OK = 0,
+    MGS_ERR_ARG = -1,          /* bad argument / unsupported layout          */
+    MGS_ERR_HIP = -2,          /* a HIP runtime call failed                  */
+    MGS_ERR_RECORD_SIZE = -3,  /* a record is larger than buf_size
+                                  (src/collectiveshuffler.h:156-159)          */
+    MGS_ERR_LOCAL_OVERFLOW = -4, /* local bypass stream ran out of room      */
+    MGS_ERR_MALFORMED = -5,    /* record does not match the layout           */
+    MGS_ERR_TIMEOUT = -6,      /* in-kernel wait gave up (device not ours?)  */
+    MGS_ERR_STATE = -7         /* call sequence error                        */
+} mgs_status;
+
+/* ---- record layout: which bytes of a wire-form record are the key --------
+ * Mirrors the template dispatch of bytestream<T> (src/serializer.h:40-223):
+ *   MGS_KEY_FIXED  K is a value type; key = key_bytes = sizeof(K)*keycount
+ *   MGS_KEY_CSTR   K is char* / const char*; key = key_count C strings, NULs
+ *                  included
+ *   MGS_VAL_VOID / MGS_VAL_FIXED / MGS_VAL_CSTR likewise for V.            */
+enum { MGS_KEY_FIXED = 0, MGS_KEY_CSTR = 1 };
+enum { MGS_VAL_VOID = 0, MGS_VAL_FIXED = 1, MGS_VAL_CSTR = 2 };
+
+typedef struct mgs_layout {
+    int32_t key_kind;
+    int32_t key_bytes; /* FIXED only */
+    int32_t key_count; /* CSTR only, >= 1 */
+    int32_t val_kind;
+    int32_t val_bytes; /* FIXED only */
+    int32_t val_count; /* CSTR only, >= 1 */
+} mgs_layout;
+
+/* ---- which kernels to run ------------------------------------------------ */
+enum {
+    MGS_ALGO_AUTO = 0,     /* fastest kernel that supports the layout        */
+    MGS_ALGO_GENERIC = 1,  /* three-pass histogram / scan / scatter, any
+                              layout, any nranks <= MGS_MAX_RANKS             */
+    MGS_ALGO_ONESWEEP16 = 2 /* single-pass chained-scan kernel for 16-byte
+                              fixed-width records, nranks <= 64               */
+};
+
+typedef struct mgs_desc {
+    int32_t nranks;       /* P: number of destinations (shuffle_size)        */
+    int32_t rank;         /* this rank; its records bypass the send image
+                             (src/collectiveshuffler.h:135-141).  -1: no
+                             bypass, all P partitions are packed             */
+    mgs_layout layout;
+    int64_t buf_size;     /* bytes per destination partition; send image is
+                             nranks*buf_size (src/collectiveshuffler.h:46)   */
+    int32_t device;       /* HIP device ordinal                              */
+    int32_t reserved;
+    uint64_t max_records; /* most records one mgs_pack_device call covers    */
+} mgs_desc;
+
+typedef struct mgs_handle mgs_handle;
+
+/* Result of one pack call = one (possibly partial) shuffle round. */
+typedef struct mgs_round {
+    uint64_t next;           /* index of the first record NOT consumed: the
+                                record that did not fit its partition
+                                (kv_to_bytes == -1, src/collectiveshuffler.h:
+                                148) and must open the next round; == n_end
+                                when everything fitted                       */
+    uint64_t packed_records; /* records written to the send image (the
+                                reference's kvcount, :163)                   */
+    uint64_t local_records;  /* records that took the local bypass           */
+    int64_t local_bytes;     /* bytes appended to d_local_out                */
+    int64_t send_offset[MGS_MAX_RANKS]; /* bytes used in each partition after
+                                this call (the reference's send_offset[],
+                                :162); entry `rank` stays 0                  */
+} mgs_round;
+
+/* Send-buffer geometry of the CollectiveShuffler / NBCollectiveShuffler
+ * constructors (src/collectiveshuffler.h:33-53, src/nbcollectiveshuffler.h:
+ * 48-67): unit_size = 4096 halved until unit_size*nranks <= comm_buf_size,
+ * buf_size = (comm_buf_size/unit_size/nranks)*unit_size, type_log_bytes = the
+ * log2 of the MPI count unit.  Returns MGS_ERR_ARG where the reference aborts
+ * ("communication buffer is too small", unit_size < 64).  Host only. */
+int mgs_geometry(int64_t comm_buf_size, int nranks, int64_t *buf_size,
+                 int *unit_size, int *type_log_bytes);
+
+/* lookup3 hashlittle on the host (src/hash.cpp:152-400) -- the same routine
+ * the kernels run, exported so callers and tests can check it without a GPU. */
+uint32_t mgs_hashlittle_host(const void *key, size_t length, uint32_t initval);
+
+/* Destination rule of BaseShuffler::get_target_rank with load balancing off
+ * (src/baseshuffler.h:275-277), evaluated with the kernels' division-free
+ * modulo.  Host only. */
+uint32_t mgs_dest_of_hash_host(uint32_t hash, uint32_t nranks);
+
+/* Create / destroy the per-rank state.  Plays the role of
+ * CollectiveShuffler's constructor + open() (src/collectiveshuffler.h:25-109):
+ * validates the geometry and allocates the device scratch the kernels need
+ * (never the send image -- the caller owns that). */
+int mgs_create(const mgs_desc *desc, mgs_handle **out);
+void mgs_destroy(mgs_handle *h);
+
+/* Message for the last failure on this handle (h == NULL: last failure of
+ * mgs_create on this thread).  Never NULL. */
+const char *mgs_last_error(const mgs_handle *h);
+
+/* The hot path: CollectiveShuffler::write (src/collectiveshuffler.h:131-166)
+ * applied to records [start, n_end) of a device-resident stream, as one
+ * kernel sequence on `stream`.
+ *
+ *   d_records   wire-form records, back to back
+ *   d_rec_off   n_end+1 byte offsets of the records inside d_records, or NULL
+ *               when the layout is fixed-width (record i at i*record_bytes)
+ *   init_offset nranks host values: bytes already in each partition (NULL =
+ *               all zero).  Lets a round be filled by several calls.
+ *   d_send_image nranks*buf_size bytes; partition d starts at d*buf_size
+ *               (src/collectiveshuffler.h:143-144)
+ *   d_local_out records whose destination is desc.rank, appended in emit
+ *               order (the out->write bypass, :135-141); capacity local_cap
+ *               bytes.  May be NULL when desc.rank == -1.
+ *   d_dest_out  optional, one byte per record of [start, n_end): its
+ *               destination rank (hashlittle(key) % nranks)
+ *   stream      hipStream_t, or NULL for the handle's own stream
+ *
+ * At most desc.max_records records are examined; the call stops early at the
+ * first record that does not fit its partition.  Blocks until the result is
+ * on the host.  Bytes of a partition beyond send_offset[] are unspecified
+ * (as in the reference, src/serializer.h:348-364). */
+int mgs_pack_device(mgs_handle *h, const void *d_records,
+                    const uint32_t *d_rec_off, uint64_t n_end, uint64_t start,
+                    const int64_t *init_offset, void *d_send_image,
+                    void *d_local_out, int64_t local_cap, uint8_t *d_dest_out,
+                    int algo, void *stream, mgs_round *out);
+
+/* Same kernels, enqueue only: returns as soon as the work is on `stream`.
+ * mgs_pack_result() then waits for that work and fetches the result. */
+int mgs_pack_device_async(mgs_handle *h, const void *d_records,
+                          const uint32_t *d_rec_off, uint64_t n_end,
+                          uint64_t start, const int64_t *init_offset,
+                          void *d_send_image, void *d_local_out,
+                          int64_t local_cap, uint8_t *d_dest_out, int algo,
+                          void *stream);
+int mgs_pack_result(mgs_handle *h, mgs_round *out);
+
+/* Name of the kernel path the last pack call on this handle ran
+ * ("generic" / "onesweep16"). */
+const char *mgs_last_algo(const mgs_handle *h);
+
+/* Device time of the dominant kernel of the last completed pack call (the
+ * one-sweep kernel, or the generic path's scatter kernel), from HIP events
+ * recorded around that launch on the stream it ran on.  Measurement aid; has
+ * no counterpart in the reference. */
+int mgs_last_kernel_ms(mgs_handle *h, float *ms);
+
+/* ---- synthetic inputs for measurement (seeded; the reference generators
+ * seed from std::random_device, generator/gen_words.cpp:85-86) -------------
+ * n records {u64 key, u64 val}: key = splitmix64 of (seed, first+i),
+ * val = first+i. */
+int mgs_synth_u64_records(void *d_out, uint64_t n, uint64_t first,
+                          uint64_t seed, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMIR_GPU_SHUFFLE_H */

@@ -1,0 +1,494 @@
+// Host side of the C ABI declared in include/mimir_gpu_shuffle.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "mgs_common.h"
+#include "mgs_generic.h"
+#include "mgs_onesweep16.h"
+
+using namespace mgs;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void) hipSetDevice(prev);
+    }
+};
+
+std::string fmt(const char *f, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof(buf), f, ap);
+    va_end(ap);
+    return std::string(buf);
+}
+
+int fixed_record_bytes(const mgs_layout &l)
+{
+    if (l.key_kind != MGS_KEY_FIXED || l.val_kind == MGS_VAL_CSTR) return 0;
+    return l.key_bytes + (l.val_kind == MGS_VAL_FIXED ? l.val_bytes : 0);
+}
+
+} // namespace
+
+struct mgs_handle {
+    mgs_desc desc;
+    int num_cus = 0;
+    uint32_t fixed_len = 0;
+    FastMod fm;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the dominant kernel
+    bool ev_valid = false;
+    Ctrl *d_ctrl = nullptr;
+    CtrlHead *h_head = nullptr; // pinned, host -> device
+    Ctrl *h_ctrl = nullptr;     // pinned, device -> host
+    // generic path scratch
+    uint32_t *d_tile_hist = nullptr;
+    uint64_t *d_tile_base = nullptr;
+    uint8_t *d_dest = nullptr;
+    // one-sweep path scratch
+    unsigned long long *d_status = nullptr;
+    // call in flight
+    bool pending = false;
+    hipStream_t pending_stream = nullptr;
+    uint64_t pending_start = 0;
+    int64_t pending_init[MGS_MAX_RANKS];
+    bool pending_empty = false;
+    const char *last_algo = "none";
+    std::string err;
+};
+
+#define MGS_HIP(h, call)                                                        \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            (h)->err = fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                 \
+            return MGS_ERR_HIP;                                                 \
+        }                                                                       \
+    } while (0)
+
+extern "C" {
+
+int mgs_geometry(int64_t comm_buf_size, int nranks, int64_t *buf_size, int *unit_size,
+                 int *type_log_bytes)
+{
+    if (nranks <= 0 || comm_buf_size <= 0) return MGS_ERR_ARG;
+    int unit = 4096; // MEMPAGE_SIZE
+    while ((int64_t) unit * (int64_t) nranks > comm_buf_size) unit /= 2;
+    if (unit < 64) return MGS_ERR_ARG;
+    const int64_t bs = (comm_buf_size / unit / nranks) * unit;
+    int tlb = 0;
+    int64_t type_bytes = 1;
+    const int64_t max_comm = (int64_t) 1 << 30; // MAX_COMM_SIZE
+    while (type_bytes * max_comm < bs * nranks) {
+        type_bytes <<= 1;
+        tlb++;
+    }
+    if (buf_size) *buf_size = bs;
+    if (unit_size) *unit_size = unit;
+    if (type_log_bytes) *type_log_bytes = tlb;
+    return MGS_OK;
+}
+
+uint32_t mgs_hashlittle_host(const void *key, size_t length, uint32_t initval)
+{
+    // initval is folded in exactly as src/hash.cpp:163 does
+    const uint8_t *k = static_cast<const uint8_t *>(key);
+    if (initval == 0) return hashlittle_bytes(k, (uint32_t) length);
+    uint32_t a, b, c;
+    a = b = c = 0xdeadbeefu + (uint32_t) length + initval;
+    size_t len = length;
+    while (len > 12) {
+        a += (uint32_t) k[0] | ((uint32_t) k[1] << 8) | ((uint32_t) k[2] << 16) | ((uint32_t) k[3] << 24);
+        b += (uint32_t) k[4] | ((uint32_t) k[5] << 8) | ((uint32_t) k[6] << 16) | ((uint32_t) k[7] << 24);
+        c += (uint32_t) k[8] | ((uint32_t) k[9] << 8) | ((uint32_t) k[10] << 16) | ((uint32_t) k[11] << 24);
+        MGS_MIX(a, b, c);
+        len -= 12;
+        k += 12;
+    }
+    if (len == 0) return c;
+    uint32_t t[3] = {0, 0, 0};
+    for (size_t i = 0; i < len; i++) t[i >> 2] |= (uint32_t) k[i] << (8 * (i & 3));
+    a += t[0];
+    b += t[1];
+    c += t[2];
+    MGS_FINAL(a, b, c);
+    return c;
+}
+
+uint32_t mgs_dest_of_hash_host(uint32_t hash, uint32_t nranks)
+{
+    if (nranks == 0) return 0;
+    const FastMod f = make_fastmod(nranks);
+    return fastmod(hash, f);
+}
+
+const char *mgs_last_error(const mgs_handle *h)
+{
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+const char *mgs_last_algo(const mgs_handle *h) { return h ? h->last_algo : "none"; }
+
+void mgs_destroy(mgs_handle *h)
+{
+    if (!h) return;
+    {
+        DeviceGuard g(h->desc.device);
+        if (h->pending && h->pending_stream) (void) hipStreamSynchronize(h->pending_stream);
+        if (h->d_ctrl) (void) hipFree(h->d_ctrl);
+        if (h->d_tile_hist) (void) hipFree(h->d_tile_hist);
+        if (h->d_tile_base) (void) hipFree(h->d_tile_base);
+        if (h->d_dest) (void) hipFree(h->d_dest);
+        if (h->d_status) (void) hipFree(h->d_status);
+        if (h->h_head) (void) hipHostFree(h->h_head);
+        if (h->h_ctrl) (void) hipHostFree(h->h_ctrl);
+        if (h->ev0) (void) hipEventDestroy(h->ev0);
+        if (h->ev1) (void) hipEventDestroy(h->ev1);
+        if (h->own_stream) (void) hipStreamDestroy(h->own_stream);
+    }
+    delete h;
+}
+
+int mgs_create(const mgs_desc *desc, mgs_handle **out)
+{
+    if (!desc || !out) {
+        g_create_error = "mgs_create: NULL argument";
+        return MGS_ERR_ARG;
+    }
+    *out = nullptr;
+    const mgs_layout &l = desc->layout;
+    if (desc->nranks < 1 || desc->nranks > MGS_MAX_RANKS) {
+        g_create_error = fmt("mgs_create: nranks %d outside [1,%d]", desc->nranks, MGS_MAX_RANKS);
+        return MGS_ERR_ARG;
+    }
+    if (desc->rank < -1 || desc->rank >= desc->nranks) {
+        g_create_error = fmt("mgs_create: rank %d outside [-1,%d)", desc->rank, desc->nranks);
+        return MGS_ERR_ARG;
+    }
+    if (desc->buf_size <= 0 || desc->max_records == 0) {
+        g_create_error = "mgs_create: buf_size and max_records must be positive";
+        return MGS_ERR_ARG;
+    }
+    if ((l.key_kind != MGS_KEY_FIXED && l.key_kind != MGS_KEY_CSTR)
+        || (l.val_kind != MGS_VAL_VOID && l.val_kind != MGS_VAL_FIXED && l.val_kind != MGS_VAL_CSTR)
+        || (l.key_kind == MGS_KEY_FIXED && l.key_bytes < 1)
+        || (l.key_kind == MGS_KEY_CSTR && l.key_count < 1)
+        || (l.val_kind == MGS_VAL_FIXED && l.val_bytes < 1)
+        || (l.val_kind == MGS_VAL_CSTR && l.val_count < 1)) {
+        g_create_error = "mgs_create: inconsistent record layout";
+        return MGS_ERR_ARG;
+    }
+    mgs_handle *h = new (std::nothrow) mgs_handle();
+    if (!h) {
+        g_create_error = "mgs_create: out of host memory";
+        return MGS_ERR_ARG;
+    }
+    h->desc = *desc;
+    h->fixed_len = (uint32_t) fixed_record_bytes(l);
+    h->fm = make_fastmod((uint32_t) desc->nranks);
+
+    auto fail = [&](hipError_t e, const char *what) {
+        g_create_error = fmt("mgs_create: %s failed: %s", what, hipGetErrorString(e));
+        mgs_destroy(h);
+        return (int) MGS_ERR_HIP;
+    };
+    DeviceGuard g(desc->device);
+    if (!g.ok) return fail(hipErrorInvalidDevice, "hipSetDevice");
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, desc->device);
+    if (e != hipSuccess) return fail(e, "hipGetDeviceProperties");
+    h->num_cus = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return fail(e, "hipStreamCreate");
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipMalloc(&h->d_ctrl, sizeof(Ctrl))) != hipSuccess) return fail(e, "hipMalloc(ctrl)");
+    if ((e = hipHostMalloc(&h->h_head, sizeof(CtrlHead), hipHostMallocDefault)) != hipSuccess)
+        return fail(e, "hipHostMalloc(head)");
+    if ((e = hipHostMalloc(&h->h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
+        return fail(e, "hipHostMalloc(ctrl)");
+    *out = h;
+    return MGS_OK;
+}
+
+static int ensure_generic_scratch(mgs_handle *h, bool need_dest)
+{
+    const uint64_t tiles = (h->desc.max_records + GEN_TILE - 1) / GEN_TILE;
+    const uint64_t cols = (uint64_t) h->desc.nranks + 1;
+    if (!h->d_tile_hist)
+        MGS_HIP(h, hipMalloc(&h->d_tile_hist, tiles * cols * sizeof(uint32_t)));
+    if (!h->d_tile_base)
+        MGS_HIP(h, hipMalloc(&h->d_tile_base, (tiles + 1) * cols * sizeof(uint64_t)));
+    if (need_dest && !h->d_dest) MGS_HIP(h, hipMalloc(&h->d_dest, h->desc.max_records));
+    return MGS_OK;
+}
+
+static int ensure_onesweep_scratch(mgs_handle *h)
+{
+    const uint64_t tiles = (h->desc.max_records + OS_TILE - 1) / OS_TILE;
+    if (!h->d_status)
+        MGS_HIP(h, hipMalloc(&h->d_status, tiles * (uint64_t) h->desc.nranks * sizeof(unsigned long long)));
+    return MGS_OK;
+}
+
+int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
+                          uint64_t n_end, uint64_t start, const int64_t *init_offset,
+                          void *d_send_image, void *d_local_out, int64_t local_cap,
+                          uint8_t *d_dest_out, int algo, void *stream_v)
+{
+    if (!h) return MGS_ERR_ARG;
+    const mgs_desc &D = h->desc;
+    const int P = D.nranks;
+    if (start > n_end) {
+        h->err = "mgs_pack_device: start > n_end";
+        return MGS_ERR_ARG;
+    }
+    if (!d_send_image || (!d_records && n_end > start)) {
+        h->err = "mgs_pack_device: NULL device buffer";
+        return MGS_ERR_ARG;
+    }
+    if (h->fixed_len == 0 && !d_rec_off) {
+        h->err = "mgs_pack_device: variable-width layout needs d_rec_off";
+        return MGS_ERR_ARG;
+    }
+    if (D.rank >= 0 && (!d_local_out || local_cap < 0)) {
+        h->err = "mgs_pack_device: rank >= 0 needs d_local_out";
+        return MGS_ERR_ARG;
+    }
+    for (int b = 0; b < P; b++) {
+        const int64_t v = init_offset ? init_offset[b] : 0;
+        if (v < 0 || v > D.buf_size) {
+            h->err = fmt("mgs_pack_device: init_offset[%d]=%lld outside [0,buf_size]", b, (long long) v);
+            return MGS_ERR_ARG;
+        }
+    }
+    DeviceGuard g(D.device);
+    if (!g.ok) {
+        h->err = "mgs_pack_device: hipSetDevice failed";
+        return MGS_ERR_HIP;
+    }
+    if (h->pending) { // one call in flight per handle
+        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+        h->pending = false;
+    }
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
+    const uint64_t n = std::min<uint64_t>(n_end - start, D.max_records);
+
+    h->pending_start = start;
+    for (int b = 0; b < MGS_MAX_RANKS; b++)
+        h->pending_init[b] = (b < P && init_offset && b != D.rank) ? init_offset[b] : 0;
+    h->pending_stream = stream;
+    h->pending_empty = (n == 0);
+    h->ev_valid = false;
+    if (n == 0) {
+        h->pending = true;
+        return MGS_OK;
+    }
+
+    // ---- choose the kernels -------------------------------------------------
+    const uint8_t *rec0 = static_cast<const uint8_t *>(d_records);
+    bool os_ok = h->fixed_len == 16 && P <= OS_MAXP && D.layout.key_kind == MGS_KEY_FIXED
+                 && D.layout.key_bytes <= 16 && (D.buf_size % 16) == 0
+                 && ((uintptr_t) rec0 % 16) == 0 && ((uintptr_t) d_send_image % 16) == 0
+                 && (D.rank < 0 || ((uintptr_t) d_local_out % 16) == 0);
+    for (int b = 0; b < P && os_ok; b++) os_ok = (h->pending_init[b] % 16) == 0;
+    if (algo == MGS_ALGO_AUTO) algo = os_ok ? MGS_ALGO_ONESWEEP16 : MGS_ALGO_GENERIC;
+    if (algo == MGS_ALGO_ONESWEEP16 && !os_ok) {
+        h->err = "mgs_pack_device: ONESWEEP16 needs 16-byte fixed records, nranks <= 64 and "
+                 "16-byte aligned buffers/offsets";
+        return MGS_ERR_ARG;
+    }
+    if (algo != MGS_ALGO_ONESWEEP16 && algo != MGS_ALGO_GENERIC) {
+        h->err = "mgs_pack_device: unknown algo";
+        return MGS_ERR_ARG;
+    }
+    if (h->fixed_len == 0 && n_end > 0) {
+        // rec_off is 32-bit: the caller keeps a batch under 4 GiB
+    }
+
+    // ---- control block ---------------------------------------------------------
+    CtrlHead *H = h->h_head;
+    memset(H, 0, sizeof(*H));
+    H->cut_index = ~0ull;
+    H->cut_tile = 0xFFFFFFFFu;
+    H->ticket = 0;
+    H->error = 0;
+    for (int b = 0; b < P; b++) {
+        if (b == D.rank) {
+            H->part_base[b] = (uint64_t)(uintptr_t) d_local_out;
+            H->part_cap[b] = local_cap;
+            H->part_init[b] = 0;
+        }
+        else {
+            H->part_base[b] = (uint64_t)(uintptr_t) d_send_image + (uint64_t) b * (uint64_t) D.buf_size;
+            H->part_cap[b] = D.buf_size;
+            H->part_init[b] = h->pending_init[b];
+        }
+    }
+    MGS_HIP(h, hipMemcpyAsync(h->d_ctrl, H, sizeof(CtrlHead), hipMemcpyHostToDevice, stream));
+
+    if (algo == MGS_ALGO_ONESWEEP16) {
+        int rc = ensure_onesweep_scratch(h);
+        if (rc) return rc;
+        OsParams p;
+        p.rec = reinterpret_cast<const uint4 *>(rec0) + start;
+        p.n = n;
+        p.first = start;
+        p.P = (uint32_t) P;
+        p.self = D.rank;
+        p.klen = (uint32_t) D.layout.key_bytes;
+        p.nbits = 1;
+        while ((1u << p.nbits) < (uint32_t) P) p.nbits++;
+        p.fm = h->fm;
+        p.ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+        p.status = h->d_status;
+        p.dest_out = d_dest_out;
+        p.ctrl = h->d_ctrl;
+        MGS_HIP(h, hipMemsetAsync(h->d_status, 0, (size_t) p.ntiles * P * sizeof(unsigned long long), stream));
+        const uint32_t grid = std::min<uint32_t>(p.ntiles, (uint32_t) h->num_cus * 2u);
+        MGS_HIP(h, hipEventRecord(h->ev0, stream));
+        hipLaunchKernelGGL(k_onesweep16, dim3(grid), dim3(OS_THREADS), 0, stream, p);
+        MGS_HIP(h, hipEventRecord(h->ev1, stream));
+        hipLaunchKernelGGL(k_os_finalize, dim3(1), dim3(64), 0, stream, p);
+        h->last_algo = "onesweep16";
+    }
+    else {
+        int rc = ensure_generic_scratch(h, d_dest_out == nullptr);
+        if (rc) return rc;
+        GenParams p;
+        p.blob = rec0;
+        p.rec_off = h->fixed_len ? nullptr : d_rec_off;
+        p.fixed_len = h->fixed_len;
+        p.first = start;
+        p.n = n;
+        p.lay = D.layout;
+        p.P = (uint32_t) P;
+        p.self = D.rank;
+        p.fm = h->fm;
+        p.ntiles = (uint32_t)((n + GEN_TILE - 1) / GEN_TILE);
+        p.tile_hist = h->d_tile_hist;
+        p.tile_base = h->d_tile_base;
+        p.dest = d_dest_out ? d_dest_out : h->d_dest;
+        p.ctrl = h->d_ctrl;
+        hipLaunchKernelGGL(k_gen_hist, dim3(p.ntiles), dim3(GEN_THREADS), 0, stream, p);
+        hipLaunchKernelGGL(k_gen_scan, dim3(1), dim3(1024), 0, stream, p);
+        MGS_HIP(h, hipEventRecord(h->ev0, stream));
+        hipLaunchKernelGGL(k_gen_scatter, dim3(p.ntiles), dim3(GEN_THREADS), 0, stream, p);
+        MGS_HIP(h, hipEventRecord(h->ev1, stream));
+        hipLaunchKernelGGL(k_gen_finalize, dim3(1), dim3(GEN_THREADS), 0, stream, p);
+        h->last_algo = "generic";
+    }
+    MGS_HIP(h, hipGetLastError());
+    MGS_HIP(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+    h->pending = true;
+    return MGS_OK;
+}
+
+int mgs_pack_result(mgs_handle *h, mgs_round *out)
+{
+    if (!h || !out) return MGS_ERR_ARG;
+    if (!h->pending) {
+        h->err = "mgs_pack_result: no pack call in flight";
+        return MGS_ERR_STATE;
+    }
+    h->pending = false;
+    const int P = h->desc.nranks;
+    memset(out, 0, sizeof(*out));
+    if (h->pending_empty) {
+        out->next = h->pending_start;
+        for (int b = 0; b < P; b++) out->send_offset[b] = h->pending_init[b];
+        return MGS_OK;
+    }
+    DeviceGuard g(h->desc.device);
+    MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    h->ev_valid = true;
+    const int derr = h->h_ctrl->head.error;
+    if (derr != 0) {
+        switch (derr) {
+        case MGS_ERR_RECORD_SIZE:
+            h->err = fmt("KV size is larger than buf_size (%lld)", (long long) h->desc.buf_size);
+            break;
+        case MGS_ERR_LOCAL_OVERFLOW: h->err = "local bypass stream overflow (local_cap too small)"; break;
+        case MGS_ERR_MALFORMED: h->err = "a record does not match the declared layout"; break;
+        case MGS_ERR_TIMEOUT: h->err = "chained scan gave up waiting for a predecessor tile"; break;
+        default: h->err = fmt("device error %d", derr);
+        }
+        return derr;
+    }
+    *out = h->h_ctrl->result;
+    for (int b = P; b < MGS_MAX_RANKS; b++) out->send_offset[b] = 0;
+    return MGS_OK;
+}
+
+int mgs_pack_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
+                    uint64_t n_end, uint64_t start, const int64_t *init_offset,
+                    void *d_send_image, void *d_local_out, int64_t local_cap,
+                    uint8_t *d_dest_out, int algo, void *stream, mgs_round *out)
+{
+    int rc = mgs_pack_device_async(h, d_records, d_rec_off, n_end, start, init_offset,
+                                   d_send_image, d_local_out, local_cap, d_dest_out, algo, stream);
+    if (rc) return rc;
+    return mgs_pack_result(h, out);
+}
+
+int mgs_last_kernel_ms(mgs_handle *h, float *ms)
+{
+    if (!h || !ms) return MGS_ERR_ARG;
+    if (!h->ev_valid) {
+        h->err = "mgs_last_kernel_ms: no completed pack call to report";
+        return MGS_ERR_STATE;
+    }
+    DeviceGuard g(h->desc.device);
+    MGS_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return MGS_OK;
+}
+
+// ---- synthetic inputs ----------------------------------------------------------
+__global__ void k_synth_u64(ulonglong2 *out, uint64_t n, uint64_t first, uint64_t seed)
+{
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t ctr = first + i;
+        uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull; // splitmix64 state after ctr+1 steps
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        out[i] = make_ulonglong2(z, ctr);
+    }
+}
+
+int mgs_synth_u64_records(void *d_out, uint64_t n, uint64_t first, uint64_t seed, int device,
+                          void *stream)
+{
+    if (!d_out && n) return MGS_ERR_ARG;
+    if (n == 0) return MGS_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return MGS_ERR_HIP;
+    const uint64_t blocks = std::min<uint64_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_synth_u64, dim3((uint32_t) blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<ulonglong2 *>(d_out), n, first, seed);
+    return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_HIP;
+}
+
+} // extern "C"

@@ -1,0 +1,83 @@
+"""The exchange step of a shuffle round over torch.distributed.
+
+Stands in for CollectiveShuffler::exchange_kv (src/collectiveshuffler.h:
+587-674): an all-to-all of the per-destination byte counts, with -1 as the
+in-band "I am done" vote (:599-621), then an all-to-all-v of the partition
+bytes into a receive image that holds source 0's bytes, then source 1's, ...
+without gaps (:630-645).
+
+On GPUs the process group is "nccl" (= RCCL): the payload is one grouped batch
+of point-to-point sends/receives straight out of the send image -- partition d
+starts at d*buf_size and only its first send_offset[d] bytes travel -- so each
+(src,dst) pair uses its own xGMI link and nothing is compacted first.  The
+same code runs on CPU tensors over "gloo".
+"""
+import torch
+import torch.distributed as dist
+
+
+def exchange_counts(send_offset, done, group=None):
+    """MPI_Alltoall of send_offset (src/collectiveshuffler.h:606-607).
+
+    send_offset: int64 tensor [P] on the group's device (bytes per destination)
+    done: this rank votes "finished" -> sends -1 to everybody (:599-603)
+    Returns (recv_count int64 [P] with -1 mapped to 0, done_count)."""
+    P = dist.get_world_size(group)
+    out = torch.empty_like(send_offset)
+    src = torch.full_like(send_offset, -1) if done else send_offset
+    dist.all_to_all_single(out, src, group=group)
+    assert out.numel() == P
+    done_count = int((out == -1).sum().item())
+    return torch.clamp(out, min=0), done_count
+
+
+def exchange_payload(send_image, send_offset, recv_count, buf_size, recv_image,
+                     group=None):
+    """MPI_Alltoallv of the partitions (src/collectiveshuffler.h:630-645).
+
+    send_image : uint8 [P*buf_size]; partition d at d*buf_size
+    send_offset: host sequence of P ints (bytes to send to each rank)
+    recv_count : host sequence of P ints (bytes coming from each rank)
+    recv_image : uint8, at least sum(recv_count) bytes; filled src-ordered
+    Returns the number of bytes received."""
+    P = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    ops, roff = [], 0
+    for peer in range(P):
+        rc = int(recv_count[peer])
+        if rc > 0:
+            if peer == me:  # cannot happen after the local bypass, kept for safety
+                recv_image[roff:roff + rc].copy_(send_image[me * buf_size:me * buf_size + rc])
+            else:
+                ops.append(dist.P2POp(dist.irecv, recv_image[roff:roff + rc],
+                                      dist.get_global_rank(group, peer) if group else peer,
+                                      group=group))
+        roff += rc
+    for peer in range(P):
+        so = int(send_offset[peer])
+        if so > 0 and peer != me:
+            ops.append(dist.P2POp(dist.isend,
+                                  send_image[peer * buf_size:peer * buf_size + so],
+                                  dist.get_global_rank(group, peer) if group else peer,
+                                  group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return roff
+
+
+def exchange_round(send_image, send_offset_host, buf_size, recv_image, done=False,
+                   group=None):
+    """One exchange_kv: counts, then payload.  Returns (recv_count list,
+    done_count, bytes_received).  When every rank voted done nothing else
+    moves (src/collectiveshuffler.h:623)."""
+    P = dist.get_world_size(group)
+    dev = send_image.device
+    so = torch.as_tensor(list(send_offset_host), dtype=torch.int64, device=dev)
+    rc, done_count = exchange_counts(so, done, group)
+    rc_host = rc.cpu().tolist()
+    if done_count >= P:
+        return rc_host, done_count, 0
+    sent = [0] * P if done else [int(x) for x in send_offset_host]
+    got = exchange_payload(send_image, sent, rc_host, buf_size, recv_image, group)
+    return rc_host, done_count, got

@@ -1,0 +1,133 @@
+"""Device-resident packer: torch tensors in, send image out, through the C ABI.
+
+torch is plumbing here (device memory, streams); all arithmetic happens in the
+HIP kernels behind include/mimir_gpu_shuffle.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class RoundResult:
+    """Host copy of one mgs_round."""
+
+    def __init__(self, r, nranks):
+        self.next = int(r.next)
+        self.packed_records = int(r.packed_records)
+        self.local_records = int(r.local_records)
+        self.local_bytes = int(r.local_bytes)
+        self.send_offset = np.array(r.send_offset[:nranks], dtype=np.int64)
+
+    def __repr__(self):
+        return (f"RoundResult(next={self.next}, packed={self.packed_records}, "
+                f"local={self.local_records}/{self.local_bytes}B, "
+                f"send_offset={self.send_offset.tolist()})")
+
+
+class DevicePacker:
+    """One rank's pack state (mgs_handle) on one GPU.
+
+    layout   capi.Layout
+    nranks   number of destinations P
+    rank     this rank, or -1 to pack all P partitions (no local bypass)
+    buf_size bytes per destination partition (reference geometry:
+             capi.geometry(COMM_BUF_SIZE, nranks)[0])
+    """
+
+    def __init__(self, layout, nranks, rank, buf_size, max_records,
+                 device=0):
+        self.lib = capi.load()
+        self.layout = layout
+        self.nranks = nranks
+        self.rank = rank
+        self.buf_size = int(buf_size)
+        self.device = int(device)
+        self.max_records = int(max_records)
+        desc = capi.Desc(nranks, rank, layout, self.buf_size, self.device, 0,
+                         self.max_records)
+        h = C.c_void_p()
+        rc = self.lib.mgs_create(C.byref(desc), C.byref(h))
+        if rc != capi.OK:
+            raise capi.MgsError(rc, self.lib.mgs_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mgs_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != capi.OK:
+            raise capi.MgsError(rc, self.lib.mgs_last_error(self.h).decode())
+
+    def last_algo(self):
+        return self.lib.mgs_last_algo(self.h).decode()
+
+    def last_kernel_ms(self):
+        """Device time of the dominant kernel of the last completed call."""
+        ms = C.c_float()
+        self._check(self.lib.mgs_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def new_send_image(self):
+        return torch.empty(self.nranks * self.buf_size, dtype=torch.uint8,
+                           device=f"cuda:{self.device}")
+
+    def _args(self, records, rec_off, n_end, start, init_offset, send_image,
+              local_out, dest_out, algo, stream):
+        if init_offset is not None:
+            init = np.ascontiguousarray(init_offset, dtype=np.int64)
+            assert init.shape[0] >= self.nranks
+            init_p = init.ctypes.data_as(C.c_void_p)
+        else:
+            init, init_p = None, None
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        local_cap = local_out.numel() if local_out is not None else 0
+        return (self.h, _ptr(records), _ptr(rec_off), n_end, start, init_p,
+                _ptr(send_image), _ptr(local_out), local_cap, _ptr(dest_out),
+                algo, C.c_void_p(stream)), init
+
+    def pack(self, records, n_end, send_image, start=0, rec_off=None,
+             init_offset=None, local_out=None, dest_out=None,
+             algo=capi.ALGO_AUTO, stream=None):
+        """Blocking CollectiveShuffler::write over records [start, n_end)."""
+        args, _keep = self._args(records, rec_off, n_end, start, init_offset,
+                                 send_image, local_out, dest_out, algo, stream)
+        r = capi.Round()
+        self._check(self.lib.mgs_pack_device(*args, C.byref(r)))
+        return RoundResult(r, self.nranks)
+
+    def pack_async(self, records, n_end, send_image, start=0, rec_off=None,
+                   init_offset=None, local_out=None, dest_out=None,
+                   algo=capi.ALGO_AUTO, stream=None):
+        args, _keep = self._args(records, rec_off, n_end, start, init_offset,
+                                 send_image, local_out, dest_out, algo, stream)
+        self._check(self.lib.mgs_pack_device_async(*args))
+
+    def result(self):
+        r = capi.Round()
+        self._check(self.lib.mgs_pack_result(self.h, C.byref(r)))
+        return RoundResult(r, self.nranks)
+
+
+def synth_u64_records(n, seed=42, first=0, device=0, out=None):
+    """n <u64,u64> records generated on the device (16*n bytes, uint8)."""
+    if out is None:
+        out = torch.empty(n * 16, dtype=torch.uint8, device=f"cuda:{device}")
+    lib = capi.load()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    rc = lib.mgs_synth_u64_records(C.c_void_p(out.data_ptr()), n, first, seed,
+                                   device, C.c_void_p(stream))
+    if rc != capi.OK:
+        raise capi.MgsError(rc, "mgs_synth_u64_records failed")
+    return out

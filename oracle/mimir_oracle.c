@@ -1,0 +1,254 @@
+/*
+ * CPU oracle for Mimir's map-side shuffle transform -- TEST INFRASTRUCTURE
+ * ONLY (see mimir_oracle.h).  Plain C restatement of the reference
+ * algorithm; every function cites the reference lines it follows.
+ */
+#include "mimir_oracle.h"
+
+#include <string.h>
+
+/* ---- lookup3 hashlittle -------------------------------------------------
+ * src/hash.cpp:14 (rot), :60-80 (mix), :107-123 (final), :152-163 (state
+ * set-up), :344-400 (byte-at-a-time body, valid for every alignment; the
+ * aligned variants at :166-343 give the same value on little-endian). */
+static inline uint32_t rotl32(uint32_t x, int k)
+{
+    return (x << k) | (x >> (32 - k));
+}
+
+static inline uint32_t le32(const uint8_t *p)
+{
+    return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16)
+           | ((uint32_t) p[3] << 24);
+}
+
+uint32_t mo_hashlittle(const void *key, size_t length, uint32_t initval)
+{
+    const uint8_t *k = (const uint8_t *) key;
+    uint32_t a, b, c;
+    a = b = c = 0xdeadbeefu + (uint32_t) length + initval;
+
+    while (length > 12) {
+        a += le32(k);
+        b += le32(k + 4);
+        c += le32(k + 8);
+        /* mix */
+        a -= c; a ^= rotl32(c, 4);  c += b;
+        b -= a; b ^= rotl32(a, 6);  a += c;
+        c -= b; c ^= rotl32(b, 8);  b += a;
+        a -= c; a ^= rotl32(c, 16); c += b;
+        b -= a; b ^= rotl32(a, 19); a += c;
+        c -= b; c ^= rotl32(b, 4);  b += a;
+        length -= 12;
+        k += 12;
+    }
+
+    if (length == 0) return c; /* :394-395, no final() for an empty tail */
+
+    /* tail: bytes 0-3 -> a, 4-7 -> b, 8-11 -> c, little-endian, zero padded */
+    uint32_t t[3] = {0, 0, 0};
+    for (size_t i = 0; i < length; i++)
+        t[i >> 2] |= (uint32_t) k[i] << (8 * (i & 3));
+    a += t[0];
+    b += t[1];
+    c += t[2];
+
+    /* final */
+    c ^= b; c -= rotl32(b, 14);
+    a ^= c; a -= rotl32(c, 11);
+    b ^= a; b -= rotl32(a, 25);
+    c ^= b; c -= rotl32(b, 16);
+    a ^= c; a -= rotl32(c, 4);
+    b ^= a; b -= rotl32(a, 14);
+    c ^= b; c -= rotl32(b, 24);
+    return c;
+}
+
+/* ---- geometry: src/collectiveshuffler.h:33-53 (MEMPAGE_SIZE = 4096 and
+ * MAX_COMM_SIZE = 2^30 from src/globals.h:33,37) ------------------------- */
+int mo_geometry(int64_t comm_buf_size, int nranks, int64_t *buf_size,
+                int *unit_size, int *type_log_bytes)
+{
+    int unit = 4096;
+    while ((int64_t) unit * (int64_t) nranks > comm_buf_size) unit /= 2;
+    if (unit < 64) return -1;
+    int64_t bs = (comm_buf_size / unit / nranks) * unit;
+    int tlb = 0;
+    int type_bytes = 1;
+    while ((int64_t) type_bytes * ((int64_t) 1 << 30) < bs * nranks) {
+        type_bytes <<= 1;
+        tlb++;
+    }
+    if (buf_size) *buf_size = bs;
+    if (unit_size) *unit_size = unit;
+    if (type_log_bytes) *type_log_bytes = tlb;
+    return 0;
+}
+
+/* bytes taken by `count` NUL-terminated strings starting at p, scanning at
+ * most `avail` bytes; -1 if they do not terminate inside avail
+ * (bytestream<char*>::size, src/serializer.h:193-198). */
+static int64_t cstr_span(const uint8_t *p, int64_t avail, int count)
+{
+    int64_t pos = 0;
+    for (int s = 0; s < count; s++) {
+        const void *z = (pos < avail) ? memchr(p + pos, 0, (size_t)(avail - pos))
+                                      : NULL;
+        if (!z) return -1;
+        pos = (const uint8_t *) z - p + 1;
+    }
+    return pos;
+}
+
+int64_t mo_key_len(const mo_layout *lay, const uint8_t *rec, int64_t rec_len)
+{
+    int64_t klen;
+    if (lay->key_kind == MO_KEY_FIXED) {
+        klen = lay->key_bytes;
+        if (klen > rec_len) return -1;
+    }
+    else {
+        klen = cstr_span(rec, rec_len, lay->key_count > 0 ? lay->key_count : 1);
+        if (klen < 0) return -1;
+    }
+    int64_t vlen;
+    switch (lay->val_kind) {
+    case MO_VAL_VOID: vlen = 0; break;
+    case MO_VAL_FIXED: vlen = lay->val_bytes; break;
+    default:
+        vlen = cstr_span(rec + klen, rec_len - klen,
+                         lay->val_count > 0 ? lay->val_count : 1);
+        if (vlen < 0) return -1;
+    }
+    if (klen + vlen != rec_len) return -1;
+    return klen;
+}
+
+static inline void rec_span(const uint64_t *rec_off, int64_t fixed_len,
+                            uint64_t i, uint64_t *off, int64_t *len)
+{
+    if (rec_off) {
+        *off = rec_off[i];
+        *len = (int64_t)(rec_off[i + 1] - rec_off[i]);
+    }
+    else {
+        *off = i * (uint64_t) fixed_len;
+        *len = fixed_len;
+    }
+}
+
+int mo_dest(const mo_layout *lay, const uint8_t *blob, const uint64_t *rec_off,
+            int64_t fixed_len, uint64_t n, uint32_t nranks, uint32_t *hash_out,
+            int32_t *dest_out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t off;
+        int64_t len;
+        rec_span(rec_off, fixed_len, i, &off, &len);
+        int64_t klen = mo_key_len(lay, blob + off, len);
+        if (klen < 0) return -1;
+        uint32_t h = mo_hashlittle(blob + off, (size_t) klen, 0);
+        if (hash_out) hash_out[i] = h;
+        if (dest_out) dest_out[i] = (int32_t)(h % nranks);
+    }
+    return 0;
+}
+
+uint64_t mo_pack_round(const mo_layout *lay, const uint8_t *blob,
+                       const uint64_t *rec_off, int64_t fixed_len, uint64_t n,
+                       uint64_t start, uint32_t nranks, int32_t self,
+                       int64_t buf_size, uint8_t *send_image,
+                       int64_t *send_offset, uint8_t *local_out,
+                       int64_t local_cap, int64_t *local_bytes,
+                       uint64_t *local_records, uint64_t *packed_records)
+{
+    int64_t lbytes = 0;
+    uint64_t lrec = 0, prec = 0;
+    uint64_t i = start;
+    for (uint32_t d = 0; d < nranks; d++) send_offset[d] = 0;
+
+    for (; i < n; i++) {
+        uint64_t off;
+        int64_t len;
+        rec_span(rec_off, fixed_len, i, &off, &len);
+        const uint8_t *rec = blob + off;
+        int64_t klen = mo_key_len(lay, rec, len);
+        if (klen < 0) return UINT64_MAX;
+        /* get_target_rank, src/baseshuffler.h:275-277 */
+        uint32_t dest = mo_hashlittle(rec, (size_t) klen, 0) % nranks;
+
+        if ((int32_t) dest == self) { /* src/collectiveshuffler.h:135-141 */
+            if (local_out) {
+                if (lbytes + len > local_cap) return UINT64_MAX;
+                memcpy(local_out + lbytes, rec, (size_t) len);
+            }
+            lbytes += len;
+            lrec++;
+            continue;
+        }
+        /* kv_to_bytes == -1  <=>  bufsize < needed (src/serializer.h:47,
+         * :90, :150): the record ends the round and opens the next one
+         * (src/collectiveshuffler.h:148-160). */
+        if (buf_size - send_offset[dest] < len) {
+            if (len > buf_size) return UINT64_MAX; /* :156-159 LOG_ERROR */
+            break;
+        }
+        if (send_image)
+            memcpy(send_image + (int64_t) dest * buf_size + send_offset[dest],
+                   rec, (size_t) len);
+        send_offset[dest] += len; /* :162 */
+        prec++;                   /* :163 kvcount */
+    }
+    if (local_bytes) *local_bytes = lbytes;
+    if (local_records) *local_records = lrec;
+    if (packed_records) *packed_records = prec;
+    return i;
+}
+
+int64_t mo_recv_image(uint32_t nranks, int32_t me, int64_t buf_size,
+                      const uint8_t *const *send_images,
+                      const int64_t *const *send_offsets, uint8_t *recv_image,
+                      int64_t *recv_count)
+{
+    int64_t pos = 0;
+    for (uint32_t src = 0; src < nranks; src++) {
+        int64_t cnt = send_offsets[src][me];
+        if (recv_count) recv_count[src] = cnt;
+        if (recv_image && cnt > 0)
+            memcpy(recv_image + pos, send_images[src] + (int64_t) me * buf_size,
+                   (size_t) cnt);
+        pos += cnt;
+    }
+    return pos;
+}
+
+int64_t mo_parse_records(const mo_layout *lay, const uint8_t *buf,
+                         int64_t nbytes, uint64_t *rec_off_out,
+                         int64_t max_records)
+{
+    int64_t pos = 0, nrec = 0;
+    while (pos < nbytes) {
+        int64_t klen, vlen;
+        /* kv_from_bytes, src/serializer.h:376-403 */
+        if (lay->key_kind == MO_KEY_FIXED)
+            klen = lay->key_bytes;
+        else
+            klen = cstr_span(buf + pos, nbytes - pos,
+                             lay->key_count > 0 ? lay->key_count : 1);
+        if (klen < 0 || pos + klen > nbytes) return -1;
+        switch (lay->val_kind) {
+        case MO_VAL_VOID: vlen = 0; break;
+        case MO_VAL_FIXED: vlen = lay->val_bytes; break;
+        default:
+            vlen = cstr_span(buf + pos + klen, nbytes - pos - klen,
+                             lay->val_count > 0 ? lay->val_count : 1);
+        }
+        if (vlen < 0 || pos + klen + vlen > nbytes) return -1;
+        if (klen + vlen == 0) return -1;
+        if (nrec >= max_records) return -1;
+        rec_off_out[nrec++] = (uint64_t) pos;
+        pos += klen + vlen;
+    }
+    rec_off_out[nrec] = (uint64_t) pos;
+    return nrec;
+}

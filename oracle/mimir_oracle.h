@@ -1,0 +1,112 @@
+/*
+ * CPU oracle for Mimir's map-side shuffle transform.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (mimir_amd/,
+ * include/) may link, import or call this file; it is the checker the
+ * tests, the smoke test and the bench's cpu_baseline leg compare the HIP
+ * path against.
+ *
+ * Each function restates, in plain C, the behaviour of the reference code
+ * cited next to it (paths relative to the reference checkout).  Records are
+ * handed over in "wire form": the bytes `Serializer::kv_to_bytes` would
+ * produce for one <key,value> pair, i.e. key bytes immediately followed by
+ * value bytes, no header, no padding (src/serializer.h:348-364).
+ */
+#ifndef MIMIR_ORACLE_H
+#define MIMIR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MO_KEY_FIXED = 0, MO_KEY_CSTR = 1 };
+enum { MO_VAL_VOID = 0, MO_VAL_FIXED = 1, MO_VAL_CSTR = 2 };
+
+/* How a wire-form record splits into key and value.
+ *   key_kind FIXED : key is key_bytes = sizeof(K)*keycount raw bytes
+ *                    (bytestream<T>, src/serializer.h:40-79)
+ *   key_kind CSTR  : key is key_count NUL-terminated strings, NULs included
+ *                    (bytestream<char*>, src/serializer.h:141-201)
+ *   val_kind VOID  : no value bytes (bytestream<void>, :203-223)
+ *   val_kind FIXED : val_bytes = sizeof(V)*valcount raw bytes
+ *   val_kind CSTR  : val_count NUL-terminated strings
+ */
+typedef struct mo_layout {
+    int32_t key_kind;
+    int32_t key_bytes;
+    int32_t key_count;
+    int32_t val_kind;
+    int32_t val_bytes;
+    int32_t val_count;
+} mo_layout;
+
+/* lookup3 hashlittle, byte-at-a-time form (src/hash.cpp:152-163, :344-400). */
+uint32_t mo_hashlittle(const void *key, size_t length, uint32_t initval);
+
+/* Send-buffer geometry of CollectiveShuffler's constructor
+ * (src/collectiveshuffler.h:33-53).  Returns 0, or -1 where the reference
+ * aborts with "communication buffer is too small" (unit_size < 64). */
+int mo_geometry(int64_t comm_buf_size, int nranks, int64_t *buf_size,
+                int *unit_size, int *type_log_bytes);
+
+/* Number of key bytes that get hashed for one wire-form record
+ * (Serializer::get_key_bytes, src/serializer.h:418-421).  -1 if the record is
+ * malformed for the layout. */
+int64_t mo_key_len(const mo_layout *lay, const uint8_t *rec, int64_t rec_len);
+
+/* hash and destination of every record:
+ *   hash = hashlittle(keybytes, keysize, 0)   (src/serializer.h:464-480)
+ *   dest = hash % (uint32_t) nranks           (src/baseshuffler.h:275-277)
+ * rec_off: n+1 byte offsets into blob, or NULL for fixed-width records of
+ * fixed_len bytes each.  hash_out / dest_out may be NULL.  Returns 0 or -1. */
+int mo_dest(const mo_layout *lay, const uint8_t *blob, const uint64_t *rec_off,
+            int64_t fixed_len, uint64_t n, uint32_t nranks, uint32_t *hash_out,
+            int32_t *dest_out);
+
+/* One round of CollectiveShuffler::write (src/collectiveshuffler.h:131-166)
+ * over records [start, n): every record whose destination is `self` is
+ * appended, in emit order, to local_out (the `out->write` bypass, :135-141);
+ * every other record is appended to partition `dest` of send_image
+ * (send_image + dest*buf_size + send_offset[dest], :143-146).  The round
+ * ends before the first record that does not fit its partition
+ * (kv_to_bytes returning -1, :148) or at n.  self = -1 disables the bypass.
+ *
+ * send_image : nranks*buf_size bytes (may be NULL: sizes only)
+ * send_offset: nranks entries, bytes used per partition on return
+ * local_out  : capacity local_cap bytes (may be NULL: sizes only)
+ * Returns the index of the first record NOT consumed (== n when all fit),
+ * or UINT64_MAX on a malformed record / a record larger than buf_size /
+ * local_out overflow. */
+uint64_t mo_pack_round(const mo_layout *lay, const uint8_t *blob,
+                       const uint64_t *rec_off, int64_t fixed_len, uint64_t n,
+                       uint64_t start, uint32_t nranks, int32_t self,
+                       int64_t buf_size, uint8_t *send_image,
+                       int64_t *send_offset, uint8_t *local_out,
+                       int64_t local_cap, int64_t *local_bytes,
+                       uint64_t *local_records, uint64_t *packed_records);
+
+/* Receive image of one exchange (src/collectiveshuffler.h:630-645): for
+ * src = 0..nranks-1 the bytes partition `me` of that source's send image,
+ * concatenated without gaps (type_log_bytes == 0).
+ * send_images[src] points at that rank's nranks*buf_size image and
+ * send_offsets[src] at its nranks offsets.  Returns bytes written. */
+int64_t mo_recv_image(uint32_t nranks, int32_t me, int64_t buf_size,
+                      const uint8_t *const *send_images,
+                      const int64_t *const *send_offsets, uint8_t *recv_image,
+                      int64_t *recv_count);
+
+/* Walk a receive image the way save_data does (src/collectiveshuffler.h:
+ * 563-585): split `nbytes` of back-to-back wire records into record offsets.
+ * rec_off_out needs room for max_records+1 entries.  Returns the record
+ * count, or -1 when a record is malformed / runs past nbytes. */
+int64_t mo_parse_records(const mo_layout *lay, const uint8_t *buf,
+                         int64_t nbytes, uint64_t *rec_off_out,
+                         int64_t max_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+"""Regenerates the golden vectors in this directory from the REFERENCE ITSELF.
+
+Runs only where /root/reference exists: oracle/Makefile compiles the
+reference's own src/hash.cpp and the bytestream<T> templates of
+src/serializer.h into oracle/_ref/libmimir_ref.so, and this script records
+their outputs on seeded inputs.  The JSON files hold inputs and expected
+outputs only (data, no reference source).
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle.oracle import Reference  # noqa: E402
+
+
+def main():
+    ref = Reference()
+    rng = np.random.default_rng(20251111)
+
+    # 1. hashlittle(key, len, 0) for every length 0..64 (four keys each) and a
+    #    few long keys, each hashed at byte misalignments 0..3 so that all
+    #    three load strategies of src/hash.cpp (:166, :286, :344) are recorded.
+    vectors = []
+    lengths = [l for l in range(0, 65) for _ in range(4)] + [
+        100, 255, 256, 257, 1000, 1023, 1024, 4097]
+    for L in lengths:
+        key = rng.integers(0, 256, size=L, dtype=np.uint8).tobytes()
+        hs = [ref.hashlittle(key, 0, misalign=a) for a in range(4)]
+        assert len(set(hs)) == 1, "reference hash depends on alignment?"
+        vectors.append({"key_hex": key.hex(), "len": L, "hash": hs[0]})
+    # printable keys in the shapes the examples emit
+    for word in [b"a", b"b", b"zz", b"hello", b"world", b"mimir", b"x" * 1023,
+                 b"Four score and seven years ago"]:
+        key = word + b"\0"
+        vectors.append({"key_hex": key.hex(), "len": len(key),
+                        "hash": ref.hashlittle(key)})
+    for v in [0, 1, 2, 0xdeadbeefcafef00d, 0xffffffffffffffff]:
+        key = int(v).to_bytes(8, "little")
+        vectors.append({"key_hex": key.hex(), "len": 8,
+                        "hash": ref.hashlittle(key)})
+    octkey = b"012345670123456"
+    for L in range(1, 16):
+        vectors.append({"key_hex": octkey[:L].hex(), "len": L,
+                        "hash": ref.hashlittle(octkey[:L])})
+    # initval != 0 (not used by the shuffle path, kept for completeness)
+    seeded = []
+    for L in (0, 5, 12, 13, 31):
+        key = rng.integers(0, 256, size=L, dtype=np.uint8).tobytes()
+        for iv in (1, 0x9e3779b9):
+            seeded.append({"key_hex": key.hex(), "len": L, "initval": iv,
+                           "hash": ref.hashlittle(key, iv)})
+    with open(os.path.join(HERE, "hashlittle_vectors.json"), "w") as f:
+        json.dump({"source": "src/hash.cpp compiled by oracle/Makefile",
+                   "initval0": vectors, "seeded": seeded}, f, indent=0)
+
+    # 2. wire forms written by bytestream<T>::to_bytes for the four record
+    #    shapes of the examples, including the "-1 when it does not fit" rule.
+    wire = []
+    for word in [b"a", b"hello", b"Zq9", b"w" * 40]:
+        for val in (1, 0x0102030405060708):
+            out = ref.kv_cstr_u64(word, val)
+            wire.append({"shape": "cstr_u64", "key": word.decode(), "val": val,
+                         "bytes_hex": out.hex()})
+        need = len(word) + 9
+        wire.append({"shape": "cstr_u64_fit", "key": word.decode(), "val": 1,
+                     "cap_exact_ok": ref.kv_cstr_u64(word, 1, cap=need) is not None,
+                     "cap_minus1_ok": ref.kv_cstr_u64(word, 1, cap=need - 1) is not None})
+    for k, v in [(0, 0), (1, 2), (0xdeadbeefcafef00d, 7), (2**64 - 1, 2**63)]:
+        wire.append({"shape": "u64_u64", "key": k, "val": v,
+                     "bytes_hex": ref.kv_u64_u64(k, v).hex()})
+    for level in (1, 4, 8, 12, 15):
+        wire.append({"shape": "chars_u64", "key": octkey.decode(),
+                     "keycount": level, "val": 1,
+                     "bytes_hex": ref.kv_chars_u64(octkey, level, 1).hex()})
+    val16 = bytes([0xaa, 0, 0, 0, 0, 0, 0, 0]) + (1234).to_bytes(8, "little")
+    for word in [b"k", b"joinkey"]:
+        wire.append({"shape": "cstr_blob16", "key": word.decode(),
+                     "val_hex": val16.hex(),
+                     "bytes_hex": ref.kv_cstr_blob16(word, val16).hex()})
+    with open(os.path.join(HERE, "wire_vectors.json"), "w") as f:
+        json.dump({"source": "bytestream<T>::to_bytes, src/serializer.h:40-223",
+                   "vectors": wire}, f, indent=0)
+    print(f"wrote {len(vectors)}+{len(seeded)} hash vectors, {len(wire)} wire vectors")
+
+
+if __name__ == "__main__":
+    main()

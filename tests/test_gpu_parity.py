@@ -1,0 +1,350 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle:
+same destination for every record, byte-identical partitions in stable emit
+order, same round boundaries.  Bit-exact: this is integer/byte work."""
+import numpy as np
+import pytest
+
+from mimir_amd import capi, datagen
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _layouts(t):
+    return (capi.Layout.make(t[0], t[1], t[2], t[3]),
+            O.Layout.make(t[0], t[1], t[2], t[3]))
+
+
+def run_and_compare(oracle, blob, offs, lay_t, n, P, rank, buf_size, algo,
+                    start=0, init=None, max_records=None, check_dest=True):
+    """One pack call on the GPU vs one oracle round.  Returns the GPU result."""
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    glay, olay = _layouts(lay_t)
+    if init is not None:
+        pytest.skip("init offsets are covered by test_append_across_calls")
+    want = oracle.pack_round(olay, blob, offs, n, start, P, rank, buf_size)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(np.ascontiguousarray(blob)).to(dev)
+    d_off = None
+    if offs is not None:
+        assert int(offs[-1]) < (1 << 32)
+        d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).to(dev)
+    pk = DevicePacker(glay, P, rank, buf_size, max_records or max(n, 1))
+    image = torch.full((P * buf_size,), 0xEE, dtype=torch.uint8, device=dev)
+    local = torch.full((max(len(blob), 16),), 0xDD, dtype=torch.uint8, device=dev) if rank >= 0 else None
+    dest = torch.full((max(n - start, 1),), 0xFF, dtype=torch.uint8, device=dev)
+    got = pk.pack(d_blob, n, image, start=start, rec_off=d_off, local_out=local,
+                  dest_out=dest, algo=algo)
+    torch.cuda.synchronize()
+    assert got.next == want["next"], (got, want["next"])
+    assert got.send_offset.tolist() == want["send_offset"].tolist()
+    assert got.packed_records == want["packed_records"]
+    assert got.local_records == want["local_records"]
+    assert got.local_bytes == want["local_bytes"]
+    img = image.cpu().numpy()
+    for p in range(P):
+        so = int(want["send_offset"][p])
+        have = img[p * buf_size:p * buf_size + so]
+        assert np.array_equal(have, want["partitions"][p]), f"partition {p} differs"
+    if rank >= 0:
+        assert np.array_equal(local.cpu().numpy()[:got.local_bytes], want["local"])
+    if check_dest:
+        _, d = oracle.dest(olay, blob, offs, n, P)
+        consumed = got.next - start
+        assert np.array_equal(dest.cpu().numpy()[:consumed].astype(np.int32),
+                              d[start:got.next])
+    algo_name = pk.last_algo()
+    pk.close()
+    return got, algo_name
+
+
+# ---- 16-byte fixed records: the one-sweep kernel ---------------------------------
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 7, 8, 13, 16, 33, 64])
+def test_onesweep16_partitions_all_ranks(oracle, P):
+    n = 20000 + P
+    blob, _, lay = datagen.u64_records(n, seed=100 + P)
+    got, name = run_and_compare(oracle, blob, None, lay, n, P, -1, 16 * n, capi.ALGO_ONESWEEP16)
+    assert name == "onesweep16" and got.next == n
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 511, 512, 4095, 4096, 4097, 8192, 12289, 70001])
+def test_onesweep16_ragged_sizes(oracle, n):
+    blob, _, lay = datagen.u64_records(n, seed=n)
+    run_and_compare(oracle, blob, None, lay, n, 8, -1, 16 * n, capi.ALGO_ONESWEEP16)
+    run_and_compare(oracle, blob, None, lay, n, 8, 3, 16 * n, capi.ALGO_ONESWEEP16)
+
+
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_onesweep16_local_bypass(oracle, rank):
+    n = 50000
+    blob, _, lay = datagen.u64_records(n, seed=5)
+    got, _ = run_and_compare(oracle, blob, None, lay, n, 8, rank, 16 * n, capi.ALGO_AUTO)
+    assert got.send_offset[rank] == 0 and got.local_records > 0
+
+
+@pytest.mark.parametrize("buf_records", [1, 7, 100, 513, 4096, 5000])
+def test_onesweep16_round_cut(oracle, buf_records):
+    """A full partition ends the round at exactly the reference's record."""
+    n = 60000
+    blob, _, lay = datagen.u64_records(n, seed=77)
+    for rank in (-1, 2):
+        got, _ = run_and_compare(oracle, blob, None, lay, n, 8, rank, 16 * buf_records,
+                                 capi.ALGO_ONESWEEP16)
+        assert got.next < n
+
+
+def test_onesweep16_rounds_chain_to_the_end(oracle):
+    """Strict reference rounds: call after call, each starting at `next`."""
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    n, P, rank, buf = 300000, 8, 5, 16 * 3000
+    blob, _, lay_t = datagen.u64_records(n, seed=9)
+    glay, olay = _layouts(lay_t)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob).to(dev)
+    pk = DevicePacker(glay, P, rank, buf, max_records=n)
+    image = pk.new_send_image()
+    local = torch.empty(len(blob), dtype=torch.uint8, device=dev)
+    start, rounds = 0, 0
+    while start < n:
+        want = oracle.pack_round(olay, blob, None, n, start, P, rank, buf)
+        got = pk.pack(d_blob, n, image, start=start, local_out=local)
+        assert got.next == want["next"] > start
+        assert got.send_offset.tolist() == want["send_offset"].tolist()
+        img = image.cpu().numpy()
+        for p in range(P):
+            so = int(want["send_offset"][p])
+            assert np.array_equal(img[p * buf:p * buf + so], want["partitions"][p])
+        assert np.array_equal(local.cpu().numpy()[:got.local_bytes], want["local"])
+        start = got.next
+        rounds += 1
+    assert rounds >= 10
+    pk.close()
+
+
+def test_append_across_calls(oracle):
+    """Filling one round with several calls (init_offset) gives the same image
+    as one call over the concatenated stream."""
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    n, P, rank = 30000, 4, 1
+    buf = 16 * n
+    blob, _, lay_t = datagen.u64_records(n, seed=21)
+    glay, olay = _layouts(lay_t)
+    want = oracle.pack_round(olay, blob, None, n, 0, P, rank, buf)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob).to(dev)
+    pk = DevicePacker(glay, P, rank, buf, max_records=n)
+    image = pk.new_send_image()
+    local = torch.empty(len(blob), dtype=torch.uint8, device=dev)
+    cuts = [0, 4097, 4098, 20000, n]
+    init = np.zeros(P, dtype=np.int64)
+    lbytes = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        for algo in (capi.ALGO_ONESWEEP16,):
+            got = pk.pack(d_blob, b, image, start=a, init_offset=init,
+                          local_out=local[lbytes:], algo=algo)
+        assert got.next == b
+        init = got.send_offset.copy()
+        lbytes += got.local_bytes
+    assert init.tolist() == want["send_offset"].tolist()
+    img = image.cpu().numpy()
+    for p in range(P):
+        so = int(want["send_offset"][p])
+        assert np.array_equal(img[p * buf:p * buf + so], want["partitions"][p])
+    assert np.array_equal(local.cpu().numpy()[:lbytes], want["local"])
+    pk.close()
+
+
+def test_onesweep16_octant_keys_level8(oracle):
+    """<char,uint64_t> with keycount 8: 8 key characters + u64 = 16 bytes."""
+    n = 40000
+    blob, _, lay = datagen.octree_records(n, level=8, seed=43)
+    run_and_compare(oracle, blob, None, lay, n, 8, 6, 16 * n, capi.ALGO_AUTO)
+
+
+@pytest.mark.parametrize("klen", [1, 3, 4, 5, 8, 11, 12, 13, 15, 16])
+def test_onesweep16_key_widths(oracle, klen):
+    """16-byte records whose key is the first klen bytes (value = the rest)."""
+    n = 9000
+    rng = np.random.default_rng(klen)
+    blob = rng.integers(0, 256, size=16 * n, dtype=np.uint8)
+    lay = (capi.KEY_FIXED, klen, capi.VAL_FIXED, 16 - klen) if klen < 16 else (
+        capi.KEY_FIXED, 16, capi.VAL_VOID, 0)
+    run_and_compare(oracle, blob, None, lay, n, 7, 2, 16 * n, capi.ALGO_ONESWEEP16)
+
+
+def test_skewed_keys_one_hot_partition(oracle):
+    """Every record to one destination: the hottest partition ends the round."""
+    n = 20000
+    rec = np.zeros((n, 2), dtype=np.uint64)
+    rec[:, 0] = 12345
+    rec[:, 1] = np.arange(n, dtype=np.uint64)
+    blob = rec.view(np.uint8).reshape(-1)
+    lay = (capi.KEY_FIXED, 8, capi.VAL_FIXED, 8)
+    got, _ = run_and_compare(oracle, blob, None, lay, n, 8, -1, 16 * 5000, capi.ALGO_ONESWEEP16)
+    assert got.next == 5000
+
+
+# ---- generic three-pass path: every layout ---------------------------------------
+
+@pytest.mark.parametrize("P,rank", [(1, -1), (2, 0), (4, 3), (7, -1), (8, 5), (64, 1), (200, 77)])
+def test_generic_words(oracle, P, rank):
+    n = 30000
+    blob, offs, lay = datagen.word_records(n, n_unique=1000, alpha=0.5, len_mean=5, seed=44)
+    got, name = run_and_compare(oracle, blob, offs, lay, n, P, rank, int(offs[-1]), capi.ALGO_GENERIC)
+    assert name == "generic" and got.next == n
+
+
+def test_generic_words_varied_lengths_and_cuts(oracle):
+    n = 25000
+    blob, offs, lay = datagen.word_records(n, n_unique=5000, alpha=1.0, len_mean=8, len_sd=2.5, seed=4)
+    for buf in (64, 1000, 4096, 65536):
+        got, _ = run_and_compare(oracle, blob, offs, lay, n, 8, 2, buf, capi.ALGO_AUTO)
+        assert got.next < n
+    # start in the middle of the stream
+    run_and_compare(oracle, blob, offs, lay, n, 8, 2, 4096, capi.ALGO_AUTO, start=12345)
+
+
+def test_generic_long_words(oracle):
+    """Words up to 1023 characters (examples/wordcount.cpp:74)."""
+    rng = np.random.default_rng(1)
+    vocab = [bytes(rng.integers(97, 123, size=L, dtype=np.uint8)) for L in
+             [1, 2, 3, 11, 12, 13, 23, 24, 25, 100, 500, 1023]]
+    ranks = rng.integers(0, len(vocab), size=5000)
+    blob, offs, lay = datagen.word_records_from(vocab, ranks)
+    run_and_compare(oracle, blob, offs, lay, 5000, 8, 0, int(offs[-1]), capi.ALGO_AUTO)
+
+
+@pytest.mark.parametrize("level", [1, 4, 7, 9, 12, 15])
+def test_generic_octant_levels(oracle, level):
+    """Odd fixed widths (level+8 bytes), unaligned records."""
+    n = 20000
+    blob, _, lay = datagen.octree_records(n, level=level, seed=level)
+    run_and_compare(oracle, blob, None, lay, n, 8, 4, (level + 8) * n, capi.ALGO_AUTO)
+    run_and_compare(oracle, blob, None, lay, n, 8, 4, (level + 8) * 333, capi.ALGO_AUTO)
+
+
+def test_generic_join_records(oracle):
+    n = 20000
+    blob, offs, lay = datagen.join_records(n, n_unique=2000, alpha=1.0, len_mean=6, len_sd=1, seed=45)
+    run_and_compare(oracle, blob, offs, lay, n, 4, 2, int(offs[-1]), capi.ALGO_AUTO)
+    run_and_compare(oracle, blob, offs, lay, n, 8, -1, 8192, capi.ALGO_AUTO)
+
+
+def test_generic_string_values(oracle):
+    """<char*,char*>: both halves NUL-terminated."""
+    rng = np.random.default_rng(3)
+    recs, offs = [], [0]
+    for _ in range(4000):
+        k = bytes(rng.integers(97, 123, size=rng.integers(1, 20), dtype=np.uint8)) + b"\0"
+        v = bytes(rng.integers(65, 91, size=rng.integers(0, 30), dtype=np.uint8)) + b"\0"
+        recs.append(k + v)
+        offs.append(offs[-1] + len(k) + len(v))
+    blob = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    offs = np.array(offs, dtype=np.uint64)
+    lay = (capi.KEY_CSTR, 0, capi.VAL_CSTR, 0)
+    run_and_compare(oracle, blob, offs, lay, 4000, 5, 3, int(offs[-1]), capi.ALGO_AUTO)
+
+
+def test_generic_equals_onesweep_on_16B(oracle):
+    n = 33333
+    blob, _, lay = datagen.u64_records(n, seed=8)
+    for buf in (16 * n, 16 * 2000):
+        a, na = run_and_compare(oracle, blob, None, lay, n, 8, 1, buf, capi.ALGO_GENERIC)
+        b, nb = run_and_compare(oracle, blob, None, lay, n, 8, 1, buf, capi.ALGO_ONESWEEP16)
+        assert (na, nb) == ("generic", "onesweep16") and a.next == b.next
+
+
+def test_window_limit_max_records(oracle):
+    """A call looks at max_records records at most."""
+    n = 10000
+    blob, _, lay = datagen.u64_records(n, seed=2)
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    glay, olay = _layouts(lay)
+    pk = DevicePacker(glay, 4, -1, 16 * n, max_records=4500)
+    d_blob = torch.from_numpy(blob).cuda()
+    image = pk.new_send_image()
+    got = pk.pack(d_blob, n, image)
+    assert got.next == 4500
+    want = oracle.pack_round(olay, blob, None, 4500, 0, 4, -1, 16 * n)
+    assert got.send_offset.tolist() == want["send_offset"].tolist()
+    pk.close()
+
+
+def test_errors_are_reported(oracle):
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    # record larger than a partition: the reference aborts with "KV size ...
+    # is larger than buf_size" (src/collectiveshuffler.h:156-159)
+    blob, offs, lay = datagen.word_records(100, n_unique=5, len_mean=30, seed=1)
+    glay, _ = _layouts(lay)
+    pk = DevicePacker(glay, 2, -1, 16, max_records=100)
+    d_blob = torch.from_numpy(blob).cuda()
+    d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+    with pytest.raises(capi.MgsError) as e:
+        pk.pack(d_blob, 100, pk.new_send_image(), rec_off=d_off)
+    assert e.value.status == capi.ERR_RECORD_SIZE
+    pk.close()
+    # a key without its NUL is not a serialisation of <char*,uint64_t>
+    bad = blob.copy()
+    bad[int(offs[1]) - 9] = 65
+    pk = DevicePacker(glay, 2, -1, 1 << 16, max_records=100)
+    with pytest.raises(capi.MgsError) as e:
+        pk.pack(torch.from_numpy(bad).cuda(), 100, pk.new_send_image(), rec_off=d_off)
+    assert e.value.status == capi.ERR_MALFORMED
+    pk.close()
+
+
+def test_synth_generator_matches_host(oracle):
+    torch = _torch()
+    from mimir_amd.packer import synth_u64_records
+    n = 10007
+    dev = synth_u64_records(n, seed=42, first=5).cpu().numpy()
+    host, _, _ = datagen.u64_records(n, seed=42, first=5)
+    assert np.array_equal(dev, host)
+
+
+def test_large_stream_properties():
+    """Full-size properties that need no oracle: every record lands exactly
+    once (per-partition checksum of checksums), each partition holds only its
+    own destination, and values stay in emit order (stability)."""
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker, synth_u64_records
+    n, P = 1 << 24, 8
+    rec = synth_u64_records(n, seed=42)
+    glay = capi.Layout.make(capi.KEY_FIXED, 8, capi.VAL_FIXED, 8)
+    buf = 16 * (n // P + n // 64)
+    pk = DevicePacker(glay, P, -1, buf, max_records=n)
+    image = pk.new_send_image()
+    dest = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    got = pk.pack(rec, n, image, dest_out=dest)
+    assert got.next == n and int(got.send_offset.sum()) == 16 * n
+    words = rec.view(torch.int64).view(n, 2)
+    total_key = int(words[:, 0].sum().item())  # wrap-around int64 sums
+    total_val = int(words[:, 1].sum().item())
+    ksum = vsum = 0
+    counts = torch.bincount(dest.to(torch.int64), minlength=P).cpu().numpy()
+    for p in range(P):
+        cnt = int(got.send_offset[p]) // 16
+        assert cnt == counts[p]
+        part = image[p * buf:p * buf + 16 * cnt].view(torch.int64).view(cnt, 2)
+        ksum += int(part[:, 0].sum().item())
+        vsum += int(part[:, 1].sum().item())
+        # stability: the value is the emit index, so it must increase strictly
+        assert bool((part[1:, 1] > part[:-1, 1]).all().item())
+        # membership: the source records with dest p, in order, are this partition
+        idx = torch.nonzero(dest == p).squeeze(1)
+        assert torch.equal(words[idx], part)
+    wrap = lambda x: (x + (1 << 63)) % (1 << 64) - (1 << 63)
+    assert wrap(ksum) == wrap(total_key) and wrap(vsum) == wrap(total_val)
+    pk.close()
