@@ -181,6 +181,18 @@ const char *mgs_last_algo(const mgs_handle *h);
  * no counterpart in the reference. */
 int mgs_last_kernel_ms(mgs_handle *h, float *ms);
 
+/* Tuning / calibration aids (no counterpart in the reference).
+ * mgs_set_tuning selects which compiled instantiation of the one-sweep kernel
+ * later pack calls run (0 = the default); mgs_tuning_name names it (NULL past
+ * the end of the list).  mgs_copy_calibration streams n_records 16-byte
+ * records from d_in to d_out with the same tile loop and nothing else, and
+ * reports the device time: what a perfect partitioner could reach here. */
+int mgs_set_tuning(mgs_handle *h, int variant);
+int mgs_debug_stats(mgs_handle *h, uint64_t out[8]); /* counters of a "-stats" variant */
+const char *mgs_tuning_name(int variant);
+int mgs_copy_calibration(mgs_handle *h, const void *d_in, void *d_out,
+                         uint64_t n_records, void *stream, float *ms);
+
 /* ---- synthetic inputs for measurement (seeded; the reference generators
  * seed from std::random_device, generator/gen_words.cpp:85-86) -------------
  * n records {u64 key, u64 val}: key = splitmix64 of (seed, first+i),

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -11,6 +12,9 @@
 #include "mgs_common.h"
 #include "mgs_generic.h"
 #include "mgs_onesweep16.h"
+#include "mgs_onesweep16s.h"
+#include "mgs_onesweep16d.h"
+#include "mgs_onesweep16e.h"
 
 using namespace mgs;
 
@@ -50,8 +54,75 @@ int fixed_record_bytes(const mgs_layout &l)
 
 } // namespace
 
+// Instantiations of the one-sweep kernel.  Entry 0 is what production calls
+// run; the rest are there to be timed against it (mgs_set_tuning).
+struct OsVariant {
+    const char *name;
+    int threads, items, blocks_per_cu, tile;
+    void (*kernel)(OsParams);
+    void (*copy)(const uint4 *, uint4 *, uint64_t, uint32_t, uint32_t *);
+};
+#define OSV(name, T, I, V, B) \
+    {name, T, I, B, T * I, k_onesweep16<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
+#define OSS(name, T, I, V, B) \
+    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16s<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
+#define OSD(name, T, I, V, B) \
+    {name, T, I, B, T * I, k_onesweep16d<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
+#define OSE(name, T, I, V, B) \
+    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16e<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
+static const OsVariant kOsVariants[] = {
+    OSV("t512x8", 512, 8, 0, 2),
+    OSV("t512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
+    OSV("t512x8-noprefetch", 512, 8, OSV_NO_PREFETCH, 2),
+    OSV("t512x8-nt", 512, 8, OSV_NT_LOAD | OSV_NT_STORE, 2),
+    OSV("t256x8", 256, 8, 0, 4),
+    OSV("t256x16", 256, 16, 0, 2),
+    OSV("t1024x8", 1024, 8, 0, 1),
+    OSV("t1024x4", 1024, 4, 0, 2),
+    OSV("t512x4", 512, 4, 0, 4),
+    OSV("t512x8-ntstore", 512, 8, OSV_NT_STORE, 2),
+    OSV("t512x8-ntload", 512, 8, OSV_NT_LOAD, 2),
+    OSV("t512x8-stats", 512, 8, OSV_STATS, 2),
+    OSV("t1024x8-stats", 1024, 8, OSV_STATS, 1),
+    OSS("s512x8", 512, 8, 0, 2),
+    OSS("s512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
+    OSS("s512x8-stats", 512, 8, OSV_STATS, 2),
+    OSS("s1024x8", 1024, 8, 0, 1),
+    OSS("s1024x8-stats", 1024, 8, OSV_STATS, 1),
+    OSS("s576x8", 576, 8, 0, 2),
+    OSS("s320x8", 320, 8, 0, 4),
+    OSS("s512x8-nt", 512, 8, OSV_NT_LOAD | OSV_NT_STORE, 2),
+    OSS("s1024x8-nt", 1024, 8, OSV_NT_LOAD | OSV_NT_STORE, 1),
+    OSS("s1024x4", 1024, 4, 0, 2),
+    OSD("d256x8", 256, 8, 0, 4),             // 23
+    OSD("d256x8-fakechain", 256, 8, OSV_FAKE_CHAIN, 4),
+    OSD("d512x8", 512, 8, 0, 2),             // 25
+    OSD("d512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
+    OSD("d1024x8", 1024, 8, 0, 1),           // 27
+    OSD("d256x8-b5", 256, 8, 0, 5),
+    OSD("d256x8-b6", 256, 8, 0, 6),          // 29
+    OSD("d256x4-b8", 256, 4, 0, 8),
+    OSD("d512x8-b3", 512, 8, 0, 3),          // 31
+    OSD("d256x16", 256, 16, 0, 2),
+    OSD("d512x4-b4", 512, 4, 0, 4),          // 33
+    OSE("e512x8", 512, 8, 0, 2),             // 34
+    OSE("e512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
+    OSE("e512x8-stats", 512, 8, OSV_STATS, 2), // 36
+    OSE("e1024x8", 1024, 8, 0, 1),
+    OSE("e1024x4", 1024, 4, 0, 1),           // 38
+    OSE("e512x4-b3", 512, 4, 0, 3),
+    OSE("e512x4-b2", 512, 4, 0, 2),          // 40
+    OSE("e256x8-b4", 256, 8, 0, 4),
+    OSE("e1024x8-stats", 1024, 8, OSV_STATS, 1), // 42
+    OSE("e768x8", 768, 8, 0, 1),
+};
+constexpr int kNumOsVariants = (int) (sizeof(kOsVariants) / sizeof(kOsVariants[0]));
+constexpr int kOsMinTile = 2048;
+constexpr int kDefaultOsVariant = 13; // "s512x8": fastest measured on MI355X (tools/tune_onesweep.py)
+
 struct mgs_handle {
     mgs_desc desc;
+    int os_variant = kDefaultOsVariant;
     int num_cus = 0;
     uint32_t fixed_len = 0;
     FastMod fm;
@@ -207,6 +278,10 @@ int mgs_create(const mgs_desc *desc, mgs_handle **out)
     h->desc = *desc;
     h->fixed_len = (uint32_t) fixed_record_bytes(l);
     h->fm = make_fastmod((uint32_t) desc->nranks);
+    if (const char *env = getenv("MGS_ONESWEEP_VARIANT")) { // tuning aid, see mgs_set_tuning
+        const int v = atoi(env);
+        if (v >= 0 && v < kNumOsVariants) h->os_variant = v;
+    }
 
     auto fail = [&](hipError_t e, const char *what) {
         g_create_error = fmt("mgs_create: %s failed: %s", what, hipGetErrorString(e));
@@ -246,7 +321,9 @@ static int ensure_generic_scratch(mgs_handle *h, bool need_dest)
 
 static int ensure_onesweep_scratch(mgs_handle *h)
 {
-    const uint64_t tiles = (h->desc.max_records + OS_TILE - 1) / OS_TILE;
+    int min_tile = kOsMinTile;
+    for (int v = 0; v < kNumOsVariants; v++) min_tile = std::min(min_tile, kOsVariants[v].tile);
+    const uint64_t tiles = (h->desc.max_records + min_tile - 1) / min_tile;
     if (!h->d_status)
         MGS_HIP(h, hipMalloc(&h->d_status, tiles * (uint64_t) h->desc.nranks * sizeof(unsigned long long)));
     return MGS_OK;
@@ -360,15 +437,18 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         p.klen = (uint32_t) D.layout.key_bytes;
         p.nbits = 1;
         while ((1u << p.nbits) < (uint32_t) P) p.nbits++;
+        p.nbits_pad = (P == 1) ? 0 : p.nbits;
         p.fm = h->fm;
-        p.ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+        const OsVariant &V = kOsVariants[h->os_variant];
+        p.tile_records = (uint32_t) V.tile;
+        p.ntiles = (uint32_t)((n + p.tile_records - 1) / p.tile_records);
         p.status = h->d_status;
         p.dest_out = d_dest_out;
         p.ctrl = h->d_ctrl;
         MGS_HIP(h, hipMemsetAsync(h->d_status, 0, (size_t) p.ntiles * P * sizeof(unsigned long long), stream));
-        const uint32_t grid = std::min<uint32_t>(p.ntiles, (uint32_t) h->num_cus * 2u);
+        const uint32_t grid = std::min<uint32_t>(p.ntiles, (uint32_t)(h->num_cus * V.blocks_per_cu));
         MGS_HIP(h, hipEventRecord(h->ev0, stream));
-        hipLaunchKernelGGL(k_onesweep16, dim3(grid), dim3(OS_THREADS), 0, stream, p);
+        hipLaunchKernelGGL(V.kernel, dim3(grid), dim3(V.threads), 0, stream, p);
         MGS_HIP(h, hipEventRecord(h->ev1, stream));
         hipLaunchKernelGGL(k_os_finalize, dim3(1), dim3(64), 0, stream, p);
         h->last_algo = "onesweep16";
@@ -450,6 +530,51 @@ int mgs_pack_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_
                                    d_send_image, d_local_out, local_cap, d_dest_out, algo, stream);
     if (rc) return rc;
     return mgs_pack_result(h, out);
+}
+
+int mgs_set_tuning(mgs_handle *h, int variant)
+{
+    if (!h) return MGS_ERR_ARG;
+    if (variant < 0 || variant >= kNumOsVariants) {
+        h->err = fmt("mgs_set_tuning: variant %d outside [0,%d)", variant, kNumOsVariants);
+        return MGS_ERR_ARG;
+    }
+    h->os_variant = variant;
+    return MGS_OK;
+}
+
+int mgs_debug_stats(mgs_handle *h, uint64_t out[8])
+{
+    if (!h || !out) return MGS_ERR_ARG;
+    for (int i = 0; i < 8; i++) out[i] = h->h_ctrl->head.stats[i];
+    return MGS_OK;
+}
+
+const char *mgs_tuning_name(int variant)
+{
+    return (variant >= 0 && variant < kNumOsVariants) ? kOsVariants[variant].name : NULL;
+}
+
+int mgs_copy_calibration(mgs_handle *h, const void *d_in, void *d_out, uint64_t n_records,
+                         void *stream_v, float *ms)
+{
+    if (!h || !d_in || !d_out || !ms || n_records == 0) return MGS_ERR_ARG;
+    DeviceGuard g(h->desc.device);
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
+    const OsVariant &V = kOsVariants[h->os_variant];
+    const uint32_t tile = (uint32_t)(V.threads * V.items);
+    const uint32_t ntiles = (uint32_t)((n_records + tile - 1) / tile);
+    uint32_t *ticket = &h->d_ctrl->head.ticket;
+    MGS_HIP(h, hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream));
+    const uint32_t grid = std::min<uint32_t>(ntiles, (uint32_t)(h->num_cus * V.blocks_per_cu));
+    MGS_HIP(h, hipEventRecord(h->ev0, stream));
+    hipLaunchKernelGGL(V.copy, dim3(grid), dim3(V.threads), 0, stream,
+                       static_cast<const uint4 *>(d_in), static_cast<uint4 *>(d_out), n_records,
+                       ntiles, ticket);
+    MGS_HIP(h, hipEventRecord(h->ev1, stream));
+    MGS_HIP(h, hipStreamSynchronize(stream));
+    MGS_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return MGS_OK;
 }
 
 int mgs_last_kernel_ms(mgs_handle *h, float *ms)

@@ -155,6 +155,7 @@ struct CtrlHead {
     uint64_t part_base[MGS_MAX_RANKS]; // device address of each partition's byte 0
     int64_t part_cap[MGS_MAX_RANKS];   // capacity in bytes
     int64_t part_init[MGS_MAX_RANKS];  // bytes already there
+    unsigned long long stats[8];       // diagnostic builds only (see OSV_STATS)
 };
 
 struct Ctrl {

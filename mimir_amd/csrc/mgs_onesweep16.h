@@ -34,28 +34,20 @@
 
 namespace mgs {
 
-constexpr int OS_THREADS = 512;
-constexpr int OS_WAVES = OS_THREADS / 64;
-constexpr int OS_ITEMS = 8;
-constexpr int OS_TILE = OS_THREADS * OS_ITEMS; // 4096 records = 64 KiB
 constexpr int OS_MAXP = 64;
 constexpr uint64_t OS_FLAG_AGG = 1ull << 62;  // value = this tile's count
 constexpr uint64_t OS_FLAG_INCL = 2ull << 62; // value = count of tiles 0..t (+ initial fill)
 constexpr uint64_t OS_VALUE_MASK = (1ull << 62) - 1;
 constexpr uint32_t OS_SPIN_LIMIT = 1u << 20; // polls with nothing new before giving up
-constexpr int OS_LOOK = 4;                   // predecessor entries fetched per poll
+constexpr int OS_LOOK = 8;                   // status loads in flight per poll
 
-// LDS carve-up (bytes): one array, 16-byte aligned pieces
-constexpr int OS_LDS_REC = OS_TILE * 16;                  // tile image
-constexpr int OS_LDS_CNT = OS_WAVES * OS_MAXP * 4;        // per (wave,dest) counts
-constexpr int OS_LDS_SLOT = OS_WAVES * OS_MAXP * 4;       // per (wave,dest) running slot
-constexpr int OS_LDS_BINSTART = (OS_MAXP + 4) * 4;        // dest -> first slot (+ total)
-constexpr int OS_LDS_GPOS = OS_MAXP * 8;                  // dest -> global record position
-constexpr int OS_LDS_PBASE = OS_MAXP * 8;                 // dest -> partition address
-constexpr int OS_LDS_PCAP = OS_MAXP * 8;                  // dest -> capacity in records
-constexpr int OS_LDS_MISC = 16;
-constexpr int OS_LDS_BYTES = OS_LDS_REC + OS_LDS_CNT + OS_LDS_SLOT + OS_LDS_BINSTART
-                             + OS_LDS_GPOS + OS_LDS_PBASE + OS_LDS_PCAP + OS_LDS_MISC;
+// Variant bits (template parameter VAR); 0 is the production kernel, the others
+// exist to price one design decision at a time on the hardware.
+constexpr int OSV_FAKE_CHAIN = 1; // timing only: no chained scan, positions are made up
+constexpr int OSV_NT_LOAD = 2;    // non-temporal record loads
+constexpr int OSV_NT_STORE = 4;   // non-temporal partition stores
+constexpr int OSV_NO_PREFETCH = 8; // load a tile only once it is this workgroup's turn
+constexpr int OSV_STATS = 16;      // diagnostic: count polls / depth / cycles of the chained scan
 
 struct OsParams {
     const uint4 *rec; // record 0 of this call
@@ -65,8 +57,10 @@ struct OsParams {
     int32_t self;
     uint32_t klen;  // key bytes (1..16)
     uint32_t nbits; // ceil(log2(P)), >= 1
+    uint32_t nbits_pad; // ceil(log2(P)), >= 0: lanes per predecessor in the chained scan = 1 << nbits_pad
     FastMod fm;
     uint32_t ntiles;
+    uint32_t tile_records;
     unsigned long long *status; // [ntiles][P]
     uint8_t *dest_out;          // optional
     Ctrl *ctrl;
@@ -82,16 +76,59 @@ __device__ __forceinline__ void os_store_status(unsigned long long *p, unsigned 
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep16(OsParams p)
+template <int THREADS, int ITEMS>
+struct OsGeom {
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr int TILE = THREADS * ITEMS;
+    // LDS carve-up (bytes): one array, 16-byte aligned pieces
+    static constexpr int REC = TILE * 16;               // tile image
+    static constexpr int CNT = 2 * WAVES * OS_MAXP * 4; // per (wave,dest) counts, two copies
+    static constexpr int SLOT = WAVES * OS_MAXP * 4;    // per (wave,dest) running slot
+    static constexpr int BINSTART = (OS_MAXP + 4) * 4;  // dest -> first slot (+ total)
+    static constexpr int GPOS = OS_MAXP * 8;            // dest -> global record position
+    static constexpr int PBASE = OS_MAXP * 8;           // dest -> partition address
+    static constexpr int PCAP = OS_MAXP * 8;            // dest -> capacity in records
+    static constexpr int MISC = 16;
+    static constexpr int BYTES = REC + CNT + SLOT + BINSTART + GPOS + PBASE + PCAP + MISC;
+};
+
+template <int ITEMS, int VAR>
+__device__ __forceinline__ void os_load_tile(const OsParams &p, uint32_t tile, int tile_records,
+                                             int w, int lane, uint4 (&r)[ITEMS])
 {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[OS_LDS_BYTES];
+    const uint64_t idx0 = (uint64_t) tile * tile_records + (uint32_t) w * (ITEMS * 64) + lane;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint64_t i = idx0 + (uint32_t) k * 64;
+        if (i < p.n) {
+            if (VAR & OSV_NT_LOAD) {
+                const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p.rec + i);
+                const unsigned long long lo = __builtin_nontemporal_load(q);
+                const unsigned long long hi = __builtin_nontemporal_load(q + 1);
+                r[k] = make_uint4((uint32_t) lo, (uint32_t)(lo >> 32), (uint32_t) hi, (uint32_t)(hi >> 32));
+            }
+            else {
+                r[k] = p.rec[i];
+            }
+        }
+        else {
+            r[k] = make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
+template <int THREADS, int ITEMS, int VAR, int MINW>
+__global__ __launch_bounds__(THREADS, MINW) void k_onesweep16(OsParams p)
+{
+    using G = OsGeom<THREADS, ITEMS>;
+    constexpr int WAVES = G::WAVES, TILE = G::TILE;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[G::BYTES];
     uint4 *srec = reinterpret_cast<uint4 *>(smem);
-    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + OS_LDS_REC);
-    volatile uint32_t *wslot = reinterpret_cast<uint32_t *>(smem + OS_LDS_REC + OS_LDS_CNT);
-    uint32_t *binstart =
-        reinterpret_cast<uint32_t *>(smem + OS_LDS_REC + OS_LDS_CNT + OS_LDS_SLOT);
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + G::REC);
+    volatile uint32_t *wslot = reinterpret_cast<uint32_t *>(smem + G::REC + G::CNT);
+    uint32_t *binstart = reinterpret_cast<uint32_t *>(smem + G::REC + G::CNT + G::SLOT);
     unsigned long long *gpos = reinterpret_cast<unsigned long long *>(
-        smem + OS_LDS_REC + OS_LDS_CNT + OS_LDS_SLOT + OS_LDS_BINSTART);
+        smem + G::REC + G::CNT + G::SLOT + G::BINSTART);
     unsigned long long *pbase = gpos + OS_MAXP;
     unsigned long long *pcap = pbase + OS_MAXP;
     volatile uint32_t *misc = reinterpret_cast<uint32_t *>(pcap + OS_MAXP);
@@ -104,28 +141,24 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep16(OsParams p)
         pbase[tid] = live ? p.ctrl->head.part_base[tid] : 0ull;
         pcap[tid] = live ? (unsigned long long) (p.ctrl->head.part_cap[tid] >> 4) : 0ull;
     }
+    for (int j = tid; j < 2 * WAVES * OS_MAXP; j += THREADS) wcnt[j] = 0;
+    if (tid == 0) misc[0] = atomicAdd(&p.ctrl->head.ticket, 1u);
+    __syncthreads();
+    uint32_t tile = misc[0];
+    uint4 r[ITEMS];
+    if (tile < p.ntiles) os_load_tile<ITEMS, VAR>(p, tile, TILE, w, lane, r);
+    int par = 0;
 
-    for (;;) {
-        if (tid == 0) misc[0] = atomicAdd(&p.ctrl->head.ticket, 1u);
-        wcnt[tid] = 0; // OS_WAVES*OS_MAXP == OS_THREADS entries
-        __syncthreads();
-        const uint32_t tile = misc[0];
-        if (tile >= p.ntiles) break;
-
-        const uint64_t idx0 = (uint64_t) tile * OS_TILE + (uint32_t) w * (OS_ITEMS * 64) + lane;
-
-        // ---- load: 8 independent 16-byte loads per lane --------------------
-        uint4 r[OS_ITEMS];
-#pragma unroll
-        for (int k = 0; k < OS_ITEMS; k++) {
-            const uint64_t i = idx0 + (uint32_t) k * 64;
-            r[k] = (i < p.n) ? p.rec[i] : make_uint4(0, 0, 0, 0);
-        }
+    while (tile < p.ntiles) {
+        // the last wave draws the next tile while it waits for its loads
+        if (tid == THREADS - 64) misc[1] = atomicAdd(&p.ctrl->head.ticket, 1u);
+        uint32_t *wc = wcnt + par * (WAVES * OS_MAXP);
+        const uint64_t idx0 = (uint64_t) tile * TILE + (uint32_t) w * (ITEMS * 64) + lane;
 
         // ---- hash, destination, rank within row -----------------------------
-        uint32_t meta[OS_ITEMS]; // dest | rank<<8 | count<<16 | valid<<31
+        uint32_t meta[ITEMS]; // dest | rank<<8 | count<<16 | valid<<31
 #pragma unroll
-        for (int k = 0; k < OS_ITEMS; k++) {
+        for (int k = 0; k < ITEMS; k++) {
             const uint64_t i = idx0 + (uint32_t) k * 64;
             const bool valid = i < p.n;
             const uint32_t h = hash_rec16(r[k].x, r[k].y, r[k].z, r[k].w, p.klen);
@@ -139,16 +172,17 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep16(OsParams p)
             }
             const uint32_t rank = lanes_below(m);
             const uint32_t cnt = (uint32_t) __popcll(m);
-            if (valid && rank == 0) atomicAdd(&wcnt[w * OS_MAXP + d], cnt);
+            if (valid && rank == 0) atomicAdd(&wc[w * OS_MAXP + d], cnt);
             meta[k] = d | (rank << 8) | (cnt << 16) | (valid ? 0x80000000u : 0u);
         }
-        __syncthreads(); // S1: wcnt complete
+        __syncthreads(); // S1: this tile's counts are complete, misc[1] is set
+        const uint32_t next = misc[1];
 
         // ---- per-destination totals, slot bases (every wave, redundantly) ---
         uint32_t tot = 0, below = 0; // lane = destination
 #pragma unroll
-        for (int ww = 0; ww < OS_WAVES; ww++) {
-            const uint32_t v = wcnt[ww * OS_MAXP + lane];
+        for (int ww = 0; ww < WAVES; ww++) {
+            const uint32_t v = wc[ww * OS_MAXP + lane];
             tot += v;
             if (ww < w) below += v;
         }
@@ -171,10 +205,13 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep16(OsParams p)
                 }
             }
         }
+        // the other copy of the counts was last read before the previous S2
+        for (int j = tid; j < WAVES * OS_MAXP; j += THREADS)
+            wcnt[(par ^ 1) * (WAVES * OS_MAXP) + j] = 0;
 
         // ---- reorder into the LDS image -------------------------------------
 #pragma unroll
-        for (int k = 0; k < OS_ITEMS; k++) {
+        for (int k = 0; k < ITEMS; k++) {
             const uint32_t d = meta[k] & 0xffu, rank = (meta[k] >> 8) & 0xffu;
             const uint32_t cnt = (meta[k] >> 16) & 0xffu;
             const bool valid = (meta[k] >> 31) != 0;
@@ -185,63 +222,128 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep16(OsParams p)
             }
         }
 
+        // ---- the registers are free again: start fetching the next tile ------
+        // (wave 0 waits until its chained scan is over: its polls must not queue
+        // behind 8 KiB of its own record loads)
+        if (!(VAR & OSV_NO_PREFETCH) && w != 0) {
+            if (next < p.ntiles) os_load_tile<ITEMS, VAR>(p, next, TILE, w, lane, r);
+        }
+
         // ---- chained scan: where does this tile start in every partition? ---
-        if (w == 0 && tile != 0) {
-            const bool live = (uint32_t) lane < P;
-            unsigned long long excl = 0;
-            int64_t look = (int64_t) tile - 1;
-            bool done = !live;
+        if (VAR & OSV_FAKE_CHAIN) {
+            if (w == 0 && tile != 0 && (uint32_t) lane < P)
+                gpos[lane] = (unsigned long long) tile * (TILE / P);
+        }
+        else if (w == 0 && tile != 0) {
+            // Lane = (j, b): predecessor slot j of a load, destination b.  One
+            // poll fetches OS_LOOK loads x tpw predecessors; every decision is
+            // wave-uniform (ballots), so the walk is a scalar loop.
+            const uint32_t Pp = 1u << p.nbits_pad;    // P rounded up to a power of two
+            const uint32_t tpw = 64u >> p.nbits_pad;  // predecessors per load
+            const uint32_t j = (uint32_t) lane >> p.nbits_pad, b = (uint32_t) lane & (Pp - 1);
+            const bool bin_ok = b < P;
+            const uint64_t gmask = (Pp == 64) ? ~0ull : ((1ull << Pp) - 1ull);
+            const uint32_t gshift = j << p.nbits_pad;
+            unsigned long long acc = 0;
+            unsigned long long st_t0 = 0;
+            uint32_t st_polls = 0, st_idle = 0;
+            if (VAR & OSV_STATS) st_t0 = __builtin_readcyclecounter();
+            int64_t look = (int64_t) tile - 1; // nearest predecessor not yet accounted for
+            bool done = false;
             uint32_t idle = 0;
-            while (__any(!done)) {
+            while (!done) {
                 unsigned long long v[OS_LOOK];
 #pragma unroll
-                for (int j = 0; j < OS_LOOK; j++) {
-                    const int64_t t = look - j;
-                    v[j] = (!done && t >= 0) ? os_load_status(p.status + (uint64_t) t * P + lane)
-                                             : 0ull;
+                for (int q = 0; q < OS_LOOK; q++) {
+                    const int64_t t = look - (int64_t)(q * tpw + j);
+                    v[q] = (bin_ok && t >= 0) ? os_load_status(p.status + (uint64_t) t * P + b)
+                                              : OS_FLAG_INCL; // before tile 0 / padding lane
+                }
+                uint32_t consumed = 0;
+                bool stop = false;
+#pragma unroll
+                for (int q = 0; q < OS_LOOK; q++) {
+                    if (stop) continue;
+                    const unsigned long long f = v[q] >> 62;
+                    const int64_t t = look - (int64_t)(q * tpw + j);
+                    const bool pad = !bin_ok;
+                    // state of predecessor (q, j): all of its destinations agree
+                    const uint64_t m_agg = __ballot(f == 1 || pad);
+                    const uint64_t m_inc = __ballot(f == 2 || pad);
+                    const bool g_agg = ((m_agg >> gshift) & gmask) == gmask;
+                    const bool g_inc = ((m_inc >> gshift) & gmask) == gmask;
+                    const uint64_t t_inc = __ballot(g_inc);
+                    const uint64_t t_wait = __ballot(!g_agg && !g_inc);
+                    const uint32_t ji = t_inc ? (uint32_t)(__ffsll((unsigned long long) t_inc) - 1) >> p.nbits_pad : 64u;
+                    const uint32_t jn = t_wait ? (uint32_t)(__ffsll((unsigned long long) t_wait) - 1) >> p.nbits_pad : 64u;
+                    const unsigned long long val = (bin_ok && t >= 0) ? (v[q] & OS_VALUE_MASK) : 0ull;
+                    if (ji < jn) { // reached an inclusive prefix: finished
+                        if (j <= ji) acc += val;
+                        done = true;
+                        stop = true;
+                    }
+                    else if (jn < 64u) { // predecessor jn of this load is not published yet
+                        if (j < jn) acc += val;
+                        consumed += jn;
+                        stop = true;
+                    }
+                    else { // tpw aggregates
+                        acc += val;
+                        consumed += tpw;
+                    }
+                }
+                look -= consumed;
+                if (VAR & OSV_STATS) {
+                    st_polls++;
+                    if (consumed == 0 && !done) st_idle++;
                 }
                 if (!done) {
-                    int used = 0;
-#pragma unroll
-                    for (int j = 0; j < OS_LOOK; j++) {
-                        if (used != j) continue;       // stopped at an earlier entry
-                        const unsigned long long f = v[j] >> 62;
-                        if (f == 0 || look - j < 0) continue; // not published yet
-                        excl += v[j] & OS_VALUE_MASK;
-                        used = j + 1;
-                        if (f == 2) {
+                    if (consumed == 0) {
+                        // Bounded wait: give up after OS_SPIN_LIMIT empty polls, and leave
+                        // at once when any other tile has already given up.
+                        ++idle;
+                        if (idle > OS_SPIN_LIMIT) {
+                            raise_error(p.ctrl, MGS_ERR_TIMEOUT);
                             done = true;
-                            break;
                         }
+                        else if ((idle & 255u) == 0
+                                 && __hip_atomic_load(&p.ctrl->head.error, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            done = true;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
                     }
-                    look -= used;
-                    if (!done) {
-                        if (used == 0) {
-                            // Bounded wait: give up after OS_SPIN_LIMIT empty polls, and
-                            // leave at once when any other tile has already given up.
-                            ++idle;
-                            if (idle > OS_SPIN_LIMIT) {
-                                raise_error(p.ctrl, MGS_ERR_TIMEOUT);
-                                done = true;
-                            }
-                            else if ((idle & 255u) == 0
-                                     && __hip_atomic_load(&p.ctrl->head.error, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                                done = true;
-                            }
-                            __builtin_amdgcn_s_sleep(4);
-                        }
-                        else {
-                            idle = 0;
-                        }
+                    else {
+                        idle = 0;
                     }
                 }
             }
-            if (live) {
-                os_store_status(p.status + (uint64_t) tile * P + lane,
-                                OS_FLAG_INCL | ((excl + tot) & OS_VALUE_MASK));
-                gpos[lane] = excl;
+            if ((VAR & OSV_STATS) && lane == 0) {
+                const unsigned long long dt = __builtin_readcyclecounter() - st_t0;
+                const unsigned long long depth = (unsigned long long) ((int64_t) tile - 1 - look);
+                atomicAdd(&p.ctrl->head.stats[0], 1ull);                        // tiles that scanned
+                atomicAdd(&p.ctrl->head.stats[1], (unsigned long long) st_polls); // polls
+                atomicAdd(&p.ctrl->head.stats[2], (unsigned long long) st_idle);  // polls with nothing new
+                atomicAdd(&p.ctrl->head.stats[3], depth);                       // predecessors summed
+                atomicAdd(&p.ctrl->head.stats[4], dt);                          // cycles inside the scan
+                atomicMax(&p.ctrl->head.stats[5], depth);
+                atomicMax(&p.ctrl->head.stats[6], dt);
+                atomicMax(&p.ctrl->head.stats[7], (unsigned long long) st_polls);
             }
+            // fold the per-slot partial sums: lanes with equal b, strides Pp..32
+            for (uint32_t o = Pp; o < 64u; o <<= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t) acc, (int) o, 64);
+                const uint32_t hi = __shfl_xor((uint32_t)(acc >> 32), (int) o, 64);
+                acc += ((unsigned long long) hi << 32) | lo;
+            }
+            if ((uint32_t) lane < P) { // j == 0 and b == lane
+                os_store_status(p.status + (uint64_t) tile * P + lane,
+                                OS_FLAG_INCL | ((acc + tot) & OS_VALUE_MASK));
+                gpos[lane] = acc;
+            }
+        }
+        if (!(VAR & OSV_NO_PREFETCH) && w == 0) {
+            if (next < p.ntiles) os_load_tile<ITEMS, VAR>(p, next, TILE, w, lane, r);
         }
         __syncthreads(); // S2: LDS image and gpos complete
 
@@ -249,8 +351,8 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep16(OsParams p)
         const uint32_t total = binstart[64];
         bool overflow = false;
 #pragma unroll
-        for (int k = 0; k < OS_ITEMS; k++) {
-            const uint32_t s = (uint32_t) k * OS_THREADS + tid;
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t s = (uint32_t) k * THREADS + tid;
             if (s < total) {
                 uint32_t b = 0;
                 for (uint32_t step = 1u << (p.nbits - 1); step > 0; step >>= 1) {
@@ -259,7 +361,16 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep16(OsParams p)
                 }
                 const unsigned long long pos = gpos[b] + (s - binstart[b]);
                 if (pos < pcap[b]) {
-                    reinterpret_cast<uint4 *>(pbase[b])[pos] = srec[s];
+                    uint4 *dst = reinterpret_cast<uint4 *>(pbase[b]) + pos;
+                    const uint4 v = srec[s];
+                    if (VAR & OSV_NT_STORE) {
+                        unsigned long long *q = reinterpret_cast<unsigned long long *>(dst);
+                        __builtin_nontemporal_store(((unsigned long long) v.y << 32) | v.x, q);
+                        __builtin_nontemporal_store(((unsigned long long) v.w << 32) | v.z, q + 1);
+                    }
+                    else {
+                        *dst = v;
+                    }
                 }
                 else if ((int32_t) b == p.self) {
                     raise_error(p.ctrl, MGS_ERR_LOCAL_OVERFLOW);
@@ -270,7 +381,43 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep16(OsParams p)
             }
         }
         if (overflow) atomicMin(&p.ctrl->head.cut_tile, tile);
-        // the next trip's first barrier keeps the image intact until every lane is done with it
+
+        if (VAR & OSV_NO_PREFETCH) {
+            if (next < p.ntiles) os_load_tile<ITEMS, VAR>(p, next, TILE, w, lane, r);
+        }
+        tile = next;
+        par ^= 1;
+        // S1 of the next trip keeps the image intact until every lane has stored its slots
+    }
+}
+
+// Calibration: the same ticketed tile loop doing nothing but load + store
+// (what this load/store structure can stream at on the device at hand).
+template <int THREADS, int ITEMS, int VAR>
+__global__ __launch_bounds__(THREADS) void k_copy16(const uint4 *in, uint4 *out, uint64_t n,
+                                                    uint32_t ntiles, uint32_t *ticket)
+{
+    constexpr int TILE = THREADS * ITEMS;
+    __shared__ uint32_t nexttile;
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) nexttile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t tile = nexttile;
+        __syncthreads();
+        if (tile >= ntiles) break;
+        uint4 r[ITEMS];
+        const uint64_t idx0 = (uint64_t) tile * TILE + tid;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint64_t i = idx0 + (uint32_t) k * THREADS;
+            r[k] = (i < n) ? in[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint64_t i = idx0 + (uint32_t) k * THREADS;
+            if (i < n) out[i] = r[k];
+        }
     }
 }
 
@@ -295,9 +442,9 @@ __global__ __launch_bounds__(64) void k_os_finalize(OsParams p)
     run[lane] = 0;
     unsigned long long e = p.n;
     if (cut != 0xFFFFFFFFu) {
-        const uint64_t t0 = (uint64_t) cut * OS_TILE;
+        const uint64_t t0 = (uint64_t) cut * p.tile_records;
         bool found = false;
-        for (int row = 0; row < OS_TILE / 64 && !found; row++) {
+        for (int row = 0; row < (int) (p.tile_records / 64) && !found; row++) {
             const uint64_t i = t0 + (uint32_t) row * 64 + lane;
             const bool valid = i < p.n;
             uint32_t d = 0;

@@ -78,6 +78,22 @@ class DevicePacker:
         self._check(self.lib.mgs_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def set_tuning(self, variant):
+        self._check(self.lib.mgs_set_tuning(self.h, variant))
+
+    def debug_stats(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.mgs_debug_stats(self.h, out))
+        return list(out)
+
+    def copy_calibration(self, src, dst, n_records):
+        """ms to stream n_records 16-byte records src -> dst (tile loop only)."""
+        ms = C.c_float()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.mgs_copy_calibration(
+            self.h, _ptr(src), _ptr(dst), n_records, C.c_void_p(stream), C.byref(ms)))
+        return ms.value
+
     def new_send_image(self):
         return torch.empty(self.nranks * self.buf_size, dtype=torch.uint8,
                            device=f"cuda:{self.device}")
