@@ -115,6 +115,10 @@ static const OsVariant kOsVariants[] = {
     OSE("e256x8-b4", 256, 8, 0, 4),
     OSE("e1024x8-stats", 1024, 8, OSV_STATS, 1), // 42
     OSE("e768x8", 768, 8, 0, 1),
+    OSS("s512x8-early", 512, 8, OSV_EARLY_AGG, 2),                  // 44
+    OSS("s512x8-early-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2),
+    OSS("s1024x8-early", 1024, 8, OSV_EARLY_AGG, 1),                // 46
+    OSS("s1024x8-early-stats", 1024, 8, OSV_EARLY_AGG | OSV_STATS, 1),
 };
 constexpr int kNumOsVariants = (int) (sizeof(kOsVariants) / sizeof(kOsVariants[0]));
 constexpr int kOsMinTile = 2048;

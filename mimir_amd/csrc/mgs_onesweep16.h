@@ -47,6 +47,7 @@ constexpr int OSV_FAKE_CHAIN = 1; // timing only: no chained scan, positions are
 constexpr int OSV_NT_LOAD = 2;    // non-temporal record loads
 constexpr int OSV_NT_STORE = 4;   // non-temporal partition stores
 constexpr int OSV_NO_PREFETCH = 8; // load a tile only once it is this workgroup's turn
+constexpr int OSV_EARLY_AGG = 32;  // the last worker wave to finish hashing publishes the tile's counts
 constexpr int OSV_STATS = 16;      // diagnostic: count polls / depth / cycles of the chained scan
 
 struct OsParams {

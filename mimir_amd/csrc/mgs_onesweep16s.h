@@ -187,7 +187,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
         pcap[tid] = live ? (unsigned long long) (p.ctrl->head.part_cap[tid] >> 4) : 0ull;
     }
     for (int j = tid; j < 2 * WORKERS * OS_MAXP; j += THREADS) wcnt[j] = 0;
-    if (tid == 0) misc[0] = atomicAdd(&p.ctrl->head.ticket, 1u);
+    if (tid == 0) {
+        misc[2] = 0;
+        misc[3] = 0;
+        misc[0] = atomicAdd(&p.ctrl->head.ticket, 1u);
+    }
     __syncthreads();
     uint32_t tile = misc[0];
     uint32_t prev = 0xFFFFFFFFu; // tile whose image waits in LDS to be stored
@@ -262,6 +266,20 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
                 if (valid && rank == 0) atomicAdd(&wc[w * OS_MAXP + d], cnt);
                 meta[k] = d | (rank << 8) | (cnt << 16) | (valid ? 0x80000000u : 0u);
             }
+            if (VAR & OSV_EARLY_AGG) {
+                // The worker wave that finishes last publishes the tile's counts at once,
+                // whether or not the scan wave is still busy with the previous tile.
+                uint32_t old = 0;
+                if (lane == 0) old = atomicAdd(const_cast<uint32_t *>(&misc[2 + par]), 1u);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old == (uint32_t)(WORKERS - 1) && tile != 0) {
+                    uint32_t t2 = 0;
+#pragma unroll
+                    for (int ww = 0; ww < WORKERS; ww++) t2 += wc[ww * OS_MAXP + lane];
+                    if ((uint32_t) lane < P)
+                        os_store_status(p.status + (uint64_t) tile * P + lane, OS_FLAG_AGG | t2);
+                }
+            }
         }
         __syncthreads(); // A: counts(tile) complete; image(prev) and position(prev) ready
         const uint32_t next = misc[1];
@@ -284,13 +302,14 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
                     gpos2[par * OS_MAXP + lane] = start;
                     os_store_status(st, OS_FLAG_INCL | (start + tot));
                 }
-                else {
+                else if (!(VAR & OSV_EARLY_AGG)) {
                     os_store_status(st, OS_FLAG_AGG | tot);
                 }
             }
             // the other copy of the counts was last read before the previous barrier B
             for (int j = lane; j < WORKERS * OS_MAXP; j += 64)
                 wcnt[(par ^ 1) * (WORKERS * OS_MAXP) + j] = 0;
+            if (lane == 0) misc[2 + (par ^ 1)] = 0;
         }
         else {
             const uint32_t incl = wave_incl_scan_u32(tot, lane);

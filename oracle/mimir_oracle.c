@@ -162,10 +162,24 @@ uint64_t mo_pack_round(const mo_layout *lay, const uint8_t *blob,
                        int64_t local_cap, int64_t *local_bytes,
                        uint64_t *local_records, uint64_t *packed_records)
 {
+    for (uint32_t d = 0; d < nranks; d++) send_offset[d] = 0;
+    return mo_pack_more(lay, blob, rec_off, fixed_len, n, start, nranks, self,
+                        buf_size, send_image, send_offset, local_out,
+                        local_cap, local_bytes, local_records, packed_records);
+}
+
+uint64_t mo_pack_more(const mo_layout *lay, const uint8_t *blob,
+                      const uint64_t *rec_off, int64_t fixed_len, uint64_t n,
+                      uint64_t start, uint32_t nranks, int32_t self,
+                      int64_t buf_size, uint8_t *send_image,
+                      int64_t *send_offset, uint8_t *local_out,
+                      int64_t local_cap, int64_t *local_bytes,
+                      uint64_t *local_records, uint64_t *packed_records)
+{
     int64_t lbytes = 0;
     uint64_t lrec = 0, prec = 0;
     uint64_t i = start;
-    for (uint32_t d = 0; d < nranks; d++) send_offset[d] = 0;
+    (void) nranks;
 
     for (; i < n; i++) {
         uint64_t off;

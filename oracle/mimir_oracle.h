@@ -88,6 +88,17 @@ uint64_t mo_pack_round(const mo_layout *lay, const uint8_t *blob,
                        int64_t local_cap, int64_t *local_bytes,
                        uint64_t *local_records, uint64_t *packed_records);
 
+/* Same loop, continuing a round that is already partly filled: send_offset
+ * holds the bytes in each partition on entry (write() called after earlier
+ * write() calls of the same round) and is advanced. */
+uint64_t mo_pack_more(const mo_layout *lay, const uint8_t *blob,
+                      const uint64_t *rec_off, int64_t fixed_len, uint64_t n,
+                      uint64_t start, uint32_t nranks, int32_t self,
+                      int64_t buf_size, uint8_t *send_image,
+                      int64_t *send_offset, uint8_t *local_out,
+                      int64_t local_cap, int64_t *local_bytes,
+                      uint64_t *local_records, uint64_t *packed_records);
+
 /* Receive image of one exchange (src/collectiveshuffler.h:630-645): for
  * src = 0..nranks-1 the bytes partition `me` of that source's send image,
  * concatenated without gaps (type_log_bytes == 0).

@@ -78,6 +78,8 @@ class Oracle:
             C.c_uint64, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p,
             C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mo_pack_more.restype = C.c_uint64
+        L.mo_pack_more.argtypes = L.mo_pack_round.argtypes
         L.mo_parse_records.restype = C.c_int64
         L.mo_parse_records.argtypes = [C.POINTER(Layout), C.c_void_p,
                                        C.c_int64, C.c_void_p, C.c_int64]

@@ -1,0 +1,105 @@
+"""Multi-rank host logic over gloo on CPU: staging, round cuts, the counts +
+payload exchange, the -1 termination vote and the receive order, checked
+against a single-process oracle simulation of the reference's shuffle.
+The pack step is the oracle here (tests.refsim.OraclePacker); the GPU pack
+itself is covered by test_gpu_parity.py and test_gpu_shuffle.py."""
+import os
+import pickle
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mimir_amd import capi, datagen
+from tests import refsim
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def make_stream(kind, rank, n):
+    if kind == "u64":
+        blob, offs, lay = datagen.u64_records(n, seed=100 + rank, first=rank * 1_000_000)
+    elif kind == "words":
+        blob, offs, lay = datagen.word_records(n, n_unique=400, alpha=1.0, len_mean=6,
+                                               len_sd=1.5, seed=7 + rank)
+    elif kind == "join":
+        blob, offs, lay = datagen.join_records(n, n_unique=300, alpha=0.8, len_mean=5,
+                                               len_sd=1, seed=9 + rank)
+    else:
+        blob, offs, lay = datagen.octree_records(n, level=11, seed=3 + rank)
+    return blob, offs, capi.Layout.make(*lay)
+
+
+def counts_for(P):
+    # ragged on purpose: one rank has nothing, one has a lot
+    return [0 if r == 1 else 4000 * (r + 1) + 37 for r in range(P)]
+
+
+def _worker(rank, P, port, kind, comm, outdir, use_gpu, counts):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=P)
+    try:
+        from mimir_amd.shuffler import GpuShuffler, ListSink
+        n = counts[rank]
+        blob, offs, lay = make_stream(kind, rank, n)
+        sink = ListSink()
+        factory = None if use_gpu else refsim.OraclePacker
+        sh = GpuShuffler(sink, lay, comm_buf_size=comm, stage_bytes=1 << 16,
+                         packer_factory=factory)
+        sh.open()
+        if offs is None:
+            offs = datagen.fixed_offsets(n, lay.fixed_len())
+        # feed in uneven slices so that staging flushes fall inside rounds
+        cuts = sorted(set([0, n // 7, n // 3, n // 2, n]))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            base = int(offs[a])
+            sh.write_records(blob[base:int(offs[b])], offs[a:b + 1] - offs[a])
+        sh.close()
+        with open(os.path.join(outdir, f"rank{rank}.pkl"), "wb") as f:
+            pickle.dump({"records": sink.records, "kvcount": sh.get_record_count(),
+                         "shuffle_times": sh.shuffle_times, "send_bytes": sh.send_bytes,
+                         "recv_bytes": sh.recv_bytes}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_case(oracle, P, kind, comm, use_gpu=False, min_rounds=3, counts=None):
+    counts = counts or counts_for(P)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(P, _free_port(), kind, comm, d, use_gpu, counts), nprocs=P, join=True)
+        got = [pickle.load(open(os.path.join(d, f"rank{r}.pkl"), "rb")) for r in range(P)]
+    streams, lay = [], None
+    for r in range(P):
+        blob, offs, lay = make_stream(kind, r, counts[r])
+        streams.append((blob, offs, counts[r]))
+    buf_size = capi.geometry(comm, P)[0]
+    sinks, stats = refsim.simulate_shuffle(oracle, lay, streams, P, buf_size)
+    assert max(s["shuffle_times"] for s in stats) >= min_rounds, "case too small to cut rounds"
+    for r in range(P):
+        assert got[r]["records"] == sinks[r], f"rank {r}: sink contents/order differ"
+        for k in ("kvcount", "shuffle_times", "send_bytes", "recv_bytes"):
+            assert got[r][k] == stats[r][k], (r, k, got[r][k], stats[r][k])
+    # every record ends on the rank its key hashes to, exactly once
+    total = sum(len(s) for s in sinks)
+    assert total == sum(counts)
+
+
+@pytest.mark.parametrize("P,kind", [(2, "u64"), (2, "words"), (3, "join"), (4, "oct")])
+def test_shuffle_matches_reference_simulation(oracle, P, kind):
+    run_case(oracle, P, kind, comm=16384)
+
+
+def test_exchange_layout_two_ranks(oracle):
+    """exchange_round alone: receive image = src-ordered concatenation."""
+    run_case(oracle, 2, "words", comm=8192)
