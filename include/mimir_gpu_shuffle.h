@@ -175,6 +175,49 @@ int mgs_pack_result(mgs_handle *h, mgs_round *out);
  * ("generic" / "onesweep16"). */
 const char *mgs_last_algo(const mgs_handle *h);
 
+/* The descriptor the handle was created with. */
+int mgs_get_desc(const mgs_handle *h, mgs_desc *out);
+
+/* ---- host-staged front end: what a Writable::write() shim calls -----------
+ * The reference serialises every pair into the send buffer inside write()
+ * (src/collectiveshuffler.h:143-146) because the caller's pointers die when
+ * the call returns.  A stager makes the same copy into a pinned host buffer,
+ * in emit order and wire form, and owns the device send image of the current
+ * round.
+ *
+ *   mgs_stager_put    append one pair (key bytes, value bytes).  0 = staged,
+ *                     1 = no room: call mgs_stager_pack, then put again.
+ *   mgs_stager_pack   move what is staged to the GPU and run the pack kernels
+ *                     on it, continuing the current round.  *drained = 1: all
+ *                     staged records were consumed.  *drained = 0: a partition
+ *                     is full (kv_to_bytes == -1, :148): exchange the round,
+ *                     call mgs_stager_round_done, call mgs_stager_pack again.
+ *                     *local_records: out->local_bytes bytes of wire-form
+ *                     records whose destination is this rank, emit order (the
+ *                     out->write bypass, :135-141); valid until the next call.
+ *   mgs_stager_send_image_host / _device
+ *                     the round's send image -- partition d at d*buf_size,
+ *                     send_offset[d] valid bytes (:143-144, :635) -- as a
+ *                     pinned host copy (for MPI_Alltoallv on host memory) or
+ *                     in place on the GPU (for RCCL / GPU-aware MPI).
+ *   mgs_stager_round_done
+ *                     the exchange is over: send_offset[*] = 0 (:657).
+ *   mgs_stager_pending records staged but not packed yet. */
+typedef struct mgs_stager mgs_stager;
+int mgs_stager_create(mgs_handle *h, int64_t stage_bytes, mgs_stager **out);
+void mgs_stager_destroy(mgs_stager *s);
+const char *mgs_stager_last_error(const mgs_stager *s);
+int mgs_stager_put(mgs_stager *s, const void *key, uint32_t klen,
+                   const void *val, uint32_t vlen);
+uint64_t mgs_stager_pending(const mgs_stager *s);
+int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records,
+                    int *drained);
+int mgs_stager_send_image_host(mgs_stager *s, const void **host_image,
+                               const int64_t **send_offset);
+int mgs_stager_send_image_device(mgs_stager *s, void **d_image,
+                                 const int64_t **send_offset);
+int mgs_stager_round_done(mgs_stager *s);
+
 /* Device time of the dominant kernel of the last completed pack call (the
  * one-sweep kernel, or the generic path's scatter kernel), from HIP events
  * recorded around that launch on the stream it ran on.  Measurement aid; has

@@ -1,0 +1,367 @@
+// mimir_gpu_shuffler.hpp -- C++ host shim: Mimir's shuffler interface on top
+// of the C ABI in mimir_gpu_shuffle.h.
+//
+// GpuShuffler<K,V> is a drop-in for CollectiveShuffler<K,V>
+// (src/collectiveshuffler.h): same constructor arguments, same virtuals
+// (open / write / close / make_progress / seek / get_record_count,
+// src/baseshuffler.h:255-265), same round, bypass and termination behaviour,
+// same error convention (message on stderr, then abort of the whole job,
+// src/log.h:70-78).  What changes is where the per-record work runs: write()
+// only copies the pair's wire form into a pinned staging buffer; hashing,
+// destination and the stable pack into the send image happen on the GPU.
+//
+// The header is self-contained so that it builds without a Mimir checkout:
+// it carries its own copy of the three small interface classes (BaseObject,
+// Writable, the DB_POS enum -- src/interface.h:18-62, :80-86) in namespace
+// mimir_gpu, and talks to the outside world through `Exchange`, a two-call
+// transport (int all-to-all, byte all-to-all-v).  Inside Mimir one derives
+// from MIMIR_NS::BaseShuffler instead and implements Exchange with
+// MPI_Alltoall / MPI_Alltoallv on the shuffler's communicator; INTEGRATION.md
+// shows that variant.
+#ifndef MIMIR_GPU_SHUFFLER_HPP
+#define MIMIR_GPU_SHUFFLER_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "mimir_gpu_shuffle.h"
+
+namespace mimir_gpu {
+
+// ---- interface mirror (src/interface.h) -------------------------------------
+enum DB_POS { DB_START, DB_END };
+
+class BaseObject {
+  public:
+    virtual ~BaseObject() {}
+    virtual int open() = 0;
+    virtual void close() = 0;
+    virtual int seek(DB_POS pos) = 0;
+    virtual uint64_t get_record_count() = 0;
+};
+
+template <typename KeyType, typename ValType>
+class Writable : virtual public BaseObject {
+  public:
+    virtual ~Writable() {}
+    virtual int write(KeyType *, ValType *) = 0;
+};
+
+// ---- transport ------------------------------------------------------------------
+// The two collectives of exchange_kv (src/collectiveshuffler.h:606-607,
+// :643-645) plus the job-wide abort of LOG_ERROR.
+class Exchange {
+  public:
+    virtual ~Exchange() {}
+    virtual int rank() const = 0;
+    virtual int size() const = 0;
+    virtual void alltoall_int(const int *send, int *recv) = 0;
+    virtual void alltoallv_bytes(const char *sendbuf, const int *scount, const int *sdispl,
+                                 char *recvbuf, const int *rcount, const int *rdispl) = 0;
+    virtual void abort(int code) { std::exit(code); }
+};
+
+// ---- wire form of one typed object (bytestream<T>, src/serializer.h:40-223) ------
+template <typename T, typename Enable = void>
+struct wire {
+    static const int kind = MGS_KEY_FIXED; // == MGS_VAL_FIXED
+    static const bool is_void = false;
+    static int size(T *, int count) { return (int) sizeof(T) * count; }
+    // contiguous bytes of `count` objects; `scratch` unused
+    static const char *bytes(T *obj, int, std::vector<char> &) { return reinterpret_cast<const char *>(obj); }
+    // rebuild the typed pointer from wire bytes; returns bytes consumed
+    static int from(char *buf, int count, T *&out, std::vector<T> &) {
+        out = reinterpret_cast<T *>(buf);
+        return (int) sizeof(T) * count;
+    }
+};
+
+template <typename T>
+struct wire<T, typename std::enable_if<std::is_same<T, char *>::value
+                                       || std::is_same<T, const char *>::value>::type> {
+    static const int kind = MGS_KEY_CSTR;
+    static const bool is_void = false;
+    static int size(T *obj, int count) {
+        int n = 0;
+        for (int i = 0; i < count; i++) n += (int) strlen(obj[i]) + 1;
+        return n;
+    }
+    static const char *bytes(T *obj, int count, std::vector<char> &scratch) {
+        if (count == 1) return obj[0];
+        scratch.clear();
+        for (int i = 0; i < count; i++) scratch.insert(scratch.end(), obj[i], obj[i] + strlen(obj[i]) + 1);
+        return scratch.data();
+    }
+    static int from(char *buf, int count, T *&out, std::vector<T> &ptrs) {
+        ptrs.resize((size_t) count);
+        int n = 0;
+        for (int i = 0; i < count; i++) {
+            ptrs[(size_t) i] = buf + n;
+            n += (int) strlen(buf + n) + 1;
+        }
+        out = ptrs.data();
+        return n;
+    }
+};
+
+struct VoidSlot {};
+template <>
+struct wire<void, void> {
+    static const int kind = MGS_VAL_VOID;
+    static const bool is_void = true;
+    static int size(void *, int) { return 0; }
+    static const char *bytes(void *, int, std::vector<char> &) { return NULL; }
+};
+
+template <typename T>
+struct ptr_store {
+    typedef std::vector<T> type;
+};
+template <>
+struct ptr_store<void> {
+    typedef std::vector<char> type;
+};
+
+// ---- the shuffler ----------------------------------------------------------------
+template <typename KeyType, typename ValType>
+class GpuShuffler : public Writable<KeyType, ValType> {
+  public:
+    // Same parameter list as CollectiveShuffler (src/collectiveshuffler.h:25-31)
+    // with the communicator replaced by an Exchange; `h` (HashBucket) is unused
+    // because load balancing is not supported.
+    GpuShuffler(Exchange *comm, Writable<KeyType, ValType> *out,
+                int (*user_hash)(KeyType *key, ValType *val, int npartition), int keycount,
+                int valcount, bool split_hint = false, void *h = NULL,
+                int64_t comm_buf_size = 0, int device = 0)
+        : comm(comm), out(out), keycount(keycount), valcount(valcount), device(device)
+    {
+        (void) split_hint;
+        (void) h;
+        shuffle_rank = comm->rank();
+        shuffle_size = comm->size();
+        if (out == NULL) fail("Output shuffler cannot be NULL!\n"); // src/baseshuffler.h:35
+        if (user_hash != NULL)
+            fail("GpuShuffler: a user hash callback runs on the host per record; "
+                 "use CollectiveShuffler for this map\n");
+        this->comm_buf_size = comm_buf_size > 0 ? comm_buf_size : env_size("MIMIR_COMM_SIZE", 64 << 20);
+        int unit = 0, tlb = 0;
+        if (mgs_geometry(this->comm_buf_size, shuffle_size, &buf_size, &unit, &tlb) != MGS_OK)
+            fail("The communication buffer is too small!\n"); // src/collectiveshuffler.h:38-41
+        if (tlb != 0) fail("GpuShuffler: MIMIR_COMM_SIZE above 1 GiB is not supported\n");
+        handle = NULL;
+        stager = NULL;
+        shuffle_times = 0;
+        done_flag = done_count = 0;
+        kvcount = 0;
+    }
+
+    virtual ~GpuShuffler() { release(); }
+
+    virtual int open()
+    {
+        mgs_desc d;
+        memset(&d, 0, sizeof(d));
+        d.nranks = shuffle_size;
+        d.rank = shuffle_rank;
+        d.layout.key_kind = wire<KeyType>::kind;
+        d.layout.key_bytes = (wire<KeyType>::kind == MGS_KEY_FIXED) ? wire<KeyType>::size(NULL, keycount) : 0;
+        d.layout.key_count = keycount;
+        d.layout.val_kind = wire<ValType>::is_void ? MGS_VAL_VOID
+                            : (wire<ValType>::kind == MGS_KEY_CSTR ? MGS_VAL_CSTR : MGS_VAL_FIXED);
+        d.layout.val_bytes = (d.layout.val_kind == MGS_VAL_FIXED) ? wire<ValType>::size(NULL, valcount) : 0;
+        d.layout.val_count = valcount;
+        d.buf_size = buf_size;
+        d.device = device;
+        const int64_t stage = env_size("MIMIR_GPU_STAGE_SIZE", this->comm_buf_size);
+        d.max_records = (uint64_t) stage; // one byte per record is the densest possible stream
+        if (mgs_create(&d, &handle) != MGS_OK) fail(mgs_last_error(NULL));
+        if (mgs_stager_create(handle, stage, &stager) != MGS_OK) fail(mgs_stager_last_error(NULL));
+        recv_buffer.resize((size_t) buf_size * (size_t) shuffle_size);
+        send_count.assign((size_t) shuffle_size, 0);
+        recv_count.assign((size_t) shuffle_size, 0);
+        a2a_s_displs.assign((size_t) shuffle_size, 0);
+        a2a_r_displs.assign((size_t) shuffle_size, 0);
+        done_flag = done_count = 0;
+        return true;
+    }
+
+    virtual int write(KeyType *key, ValType *val)
+    {
+        const int klen = wire<KeyType>::size(key, keycount);
+        const int vlen = wire<ValType>::size(val, valcount);
+        const char *kb = wire<KeyType>::bytes(key, keycount, key_scratch);
+        const char *vb = wire<ValType>::bytes(val, valcount, val_scratch);
+        int rc = mgs_stager_put(stager, kb, (uint32_t) klen, vb, (uint32_t) vlen);
+        if (rc == 1) {
+            drain();
+            rc = mgs_stager_put(stager, kb, (uint32_t) klen, vb, (uint32_t) vlen);
+        }
+        if (rc != MGS_OK) fail(mgs_stager_last_error(stager));
+        return true;
+    }
+
+    virtual void close()
+    {
+        wait();
+        release();
+    }
+
+    // exchange_kv() for the blocking shuffler (src/collectiveshuffler.h:168)
+    virtual void make_progress(bool issue_new = false)
+    {
+        (void) issue_new;
+        drain();
+        exchange_kv();
+    }
+
+    virtual int seek(DB_POS) { return false; }
+    virtual uint64_t get_record_count() { return kvcount; } // src/baseshuffler.h:265
+
+    int get_shuffle_times() const { return shuffle_times; }
+
+  protected:
+    // Pack everything staged; a full partition ends the round
+    // (src/collectiveshuffler.h:148-160).
+    void drain()
+    {
+        for (;;) {
+            mgs_round r;
+            const void *local = NULL;
+            int drained = 0;
+            if (mgs_stager_pack(stager, &r, &local, &drained) != MGS_OK) fail(mgs_stager_last_error(stager));
+            kvcount += r.packed_records;
+            if (r.local_bytes > 0) // out->write at emit time, :135-141
+                deliver(const_cast<char *>(static_cast<const char *>(local)), r.local_bytes);
+            if (drained) break;
+            exchange_kv();
+        }
+    }
+
+    // src/collectiveshuffler.h:587-674
+    void exchange_kv()
+    {
+        const void *image = NULL;
+        const int64_t *send_offset = NULL;
+        if (mgs_stager_send_image_host(stager, &image, &send_offset) != MGS_OK)
+            fail(mgs_stager_last_error(stager));
+        for (int i = 0; i < shuffle_size; i++) send_count[(size_t) i] = done_flag ? -1 : (int) send_offset[i];
+        comm->alltoall_int(send_count.data(), recv_count.data());
+        done_count = 0;
+        for (int i = 0; i < shuffle_size; i++) {
+            if (recv_count[(size_t) i] == -1) {
+                done_count++;
+                recv_count[(size_t) i] = 0;
+            }
+            if (send_count[(size_t) i] == -1) send_count[(size_t) i] = 0;
+        }
+        if (done_count >= shuffle_size) return;
+        int64_t recvcount = 0;
+        for (int i = 0; i < shuffle_size; i++) {
+            a2a_s_displs[(size_t) i] = (int) (i * buf_size);
+            a2a_r_displs[(size_t) i] = (int) recvcount;
+            recvcount += recv_count[(size_t) i];
+        }
+        comm->alltoallv_bytes(static_cast<const char *>(image), send_count.data(), a2a_s_displs.data(),
+                              recv_buffer.data(), recv_count.data(), a2a_r_displs.data());
+        if (recvcount > 0) deliver(recv_buffer.data(), recvcount); // save_data, :563-585
+        mgs_stager_round_done(stager);
+        shuffle_times += 1;
+    }
+
+    // src/collectiveshuffler.h:528-561
+    void wait()
+    {
+        drain();
+        while (sendcount() > 0 || shuffle_times == 0) exchange_kv();
+        done_flag = 1;
+        do {
+            exchange_kv();
+        } while (done_count < shuffle_size);
+    }
+
+    uint64_t sendcount()
+    {
+        void *d = NULL;
+        const int64_t *so = NULL;
+        mgs_stager_send_image_device(stager, &d, &so);
+        uint64_t n = 0;
+        for (int i = 0; i < shuffle_size; i++) n += (uint64_t) so[i];
+        return n;
+    }
+
+    // Walk back-to-back wire records and hand each to `out`
+    // (kv_from_bytes, src/serializer.h:376-403).
+    void deliver(char *buf, int64_t nbytes)
+    {
+        int64_t pos = 0;
+        while (pos < nbytes) {
+            KeyType *key = NULL;
+            pos += wire<KeyType>::from(buf + pos, keycount, key, key_ptrs);
+            ValType *val = NULL;
+            pos += val_from(buf + pos, val, std::integral_constant<bool, wire<ValType>::is_void>());
+            out->write(key, val);
+        }
+    }
+
+    int val_from(char *, ValType *&val, std::true_type)
+    {
+        val = NULL;
+        return 0;
+    }
+    int val_from(char *buf, ValType *&val, std::false_type)
+    {
+        return wire<ValType>::from(buf, valcount, val, val_ptrs);
+    }
+
+    void release()
+    {
+        if (stager) mgs_stager_destroy(stager);
+        if (handle) mgs_destroy(handle);
+        stager = NULL;
+        handle = NULL;
+    }
+
+    // LOG_ERROR: "rank[size] file:line message" on stderr, then abort the job
+    void fail(const char *msg)
+    {
+        fprintf(stderr, "%d[%d] %s: %s", shuffle_rank, shuffle_size, "GpuShuffler", msg);
+        fflush(stderr);
+        comm->abort(1);
+        std::abort();
+    }
+
+    // size with the b/k/m/g suffixes Mimir's env parser accepts (src/mimir.cpp:75-131)
+    static int64_t env_size(const char *name, int64_t dflt)
+    {
+        const char *v = getenv(name);
+        if (!v || !*v) return dflt;
+        char *end = NULL;
+        double x = strtod(v, &end);
+        int64_t mul = 1;
+        if (end && (*end == 'k' || *end == 'K')) mul = 1024;
+        else if (end && (*end == 'm' || *end == 'M')) mul = 1024 * 1024;
+        else if (end && (*end == 'g' || *end == 'G')) mul = 1024LL * 1024 * 1024;
+        return (int64_t)(x * (double) mul);
+    }
+
+    Exchange *comm;
+    Writable<KeyType, ValType> *out;
+    int keycount, valcount, device;
+    int shuffle_rank, shuffle_size, shuffle_times;
+    int done_flag, done_count;
+    uint64_t kvcount;
+    int64_t comm_buf_size, buf_size;
+    mgs_handle *handle;
+    mgs_stager *stager;
+    std::vector<char> recv_buffer, key_scratch, val_scratch;
+    std::vector<int> send_count, recv_count, a2a_s_displs, a2a_r_displs;
+    typename ptr_store<KeyType>::type key_ptrs;
+    typename ptr_store<ValType>::type val_ptrs;
+};
+
+} // namespace mimir_gpu
+#endif

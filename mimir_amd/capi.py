@@ -81,6 +81,19 @@ SYMBOLS = {
     "mgs_debug_stats": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "mgs_copy_calibration": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP,
                                        C.POINTER(C.c_float)]),
+    "mgs_get_desc": (C.c_int, [_VP, C.POINTER(Desc)]),
+    "mgs_stager_create": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
+    "mgs_stager_destroy": (None, [_VP]),
+    "mgs_stager_last_error": (C.c_char_p, [_VP]),
+    "mgs_stager_put": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32]),
+    "mgs_stager_pending": (C.c_uint64, [_VP]),
+    "mgs_stager_pack": (C.c_int, [_VP, C.POINTER(Round), C.POINTER(_VP),
+                                  C.POINTER(C.c_int)]),
+    "mgs_stager_send_image_host": (C.c_int, [_VP, C.POINTER(_VP),
+                                             C.POINTER(C.POINTER(C.c_int64))]),
+    "mgs_stager_send_image_device": (C.c_int, [_VP, C.POINTER(_VP),
+                                               C.POINTER(C.POINTER(C.c_int64))]),
+    "mgs_stager_round_done": (C.c_int, [_VP]),
     "mgs_synth_u64_records": (C.c_int, [_VP, C.c_uint64, C.c_uint64,
                                         C.c_uint64, C.c_int, _VP]),
 }

@@ -536,6 +536,13 @@ int mgs_pack_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_
     return mgs_pack_result(h, out);
 }
 
+int mgs_get_desc(const mgs_handle *h, mgs_desc *out)
+{
+    if (!h || !out) return MGS_ERR_ARG;
+    *out = h->desc;
+    return MGS_OK;
+}
+
 int mgs_set_tuning(mgs_handle *h, int variant)
 {
     if (!h) return MGS_ERR_ARG;

@@ -1,0 +1,284 @@
+// Host-staged front end of the pack path: what a Writable::write() shim needs.
+//
+// The reference copies every pair into the send buffer inside write()
+// (kv_to_bytes, src/collectiveshuffler.h:143-146) because the caller's
+// pointers are only valid during the call.  Here the same copy goes into a
+// pinned host staging buffer, in emit order and in wire form; a pack call
+// moves the staged batch to the GPU, runs hash -> destination -> stable pack
+// into the device send image and brings back the local-bypass records.
+// Built on the public C ABI only (mgs_pack_device + HIP memory calls).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "mimir_gpu_shuffle.h"
+
+struct mgs_stager {
+    mgs_handle *h = nullptr;
+    mgs_desc desc;
+    int64_t cap = 0;           // staging bytes
+    uint64_t max_rec = 0;      // staging records
+    bool fixed = false;
+    uint8_t *h_stage = nullptr; // pinned: wire-form records
+    uint32_t *h_off = nullptr;  // pinned: record offsets (variable-width layouts)
+    uint8_t *d_stage = nullptr;
+    uint32_t *d_off = nullptr;
+    uint8_t *d_image = nullptr; // nranks * buf_size
+    uint8_t *d_local = nullptr; // local-bypass records of one pack call
+    uint8_t *h_image = nullptr; // pinned mirror of the send image (host exchange)
+    uint8_t *h_local = nullptr; // pinned
+    int64_t used = 0;
+    uint64_t nrec = 0;
+    uint64_t cursor = 0; // first staged record not packed yet
+    bool uploaded = false;
+    int64_t send_offset[MGS_MAX_RANKS];
+    hipStream_t stream = nullptr;
+    std::string err;
+};
+
+namespace {
+thread_local std::string g_stager_error;
+
+std::string sfmt(const char *f, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof(buf), f, ap);
+    va_end(ap);
+    return std::string(buf);
+}
+
+int fixed_len(const mgs_layout &l)
+{
+    if (l.key_kind != MGS_KEY_FIXED || l.val_kind == MGS_VAL_CSTR) return 0;
+    return l.key_bytes + (l.val_kind == MGS_VAL_FIXED ? l.val_bytes : 0);
+}
+} // namespace
+
+#define STG_HIP(s, call)                                                         \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            (s)->err = sfmt("%s failed: %s", #call, hipGetErrorString(e_));      \
+            return MGS_ERR_HIP;                                                  \
+        }                                                                        \
+    } while (0)
+
+extern "C" {
+
+const char *mgs_stager_last_error(const mgs_stager *s)
+{
+    return s ? s->err.c_str() : g_stager_error.c_str();
+}
+
+void mgs_stager_destroy(mgs_stager *s)
+{
+    if (!s) return;
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    (void) hipSetDevice(s->desc.device);
+    if (s->stream) (void) hipStreamSynchronize(s->stream);
+    if (s->h_stage) (void) hipHostFree(s->h_stage);
+    if (s->h_off) (void) hipHostFree(s->h_off);
+    if (s->h_image) (void) hipHostFree(s->h_image);
+    if (s->h_local) (void) hipHostFree(s->h_local);
+    if (s->d_stage) (void) hipFree(s->d_stage);
+    if (s->d_off) (void) hipFree(s->d_off);
+    if (s->d_image) (void) hipFree(s->d_image);
+    if (s->d_local) (void) hipFree(s->d_local);
+    if (s->stream) (void) hipStreamDestroy(s->stream);
+    if (prev >= 0) (void) hipSetDevice(prev);
+    delete s;
+}
+
+int mgs_stager_create(mgs_handle *h, int64_t stage_bytes, mgs_stager **out)
+{
+    if (!h || !out || stage_bytes < 64) {
+        g_stager_error = "mgs_stager_create: bad argument";
+        return MGS_ERR_ARG;
+    }
+    *out = nullptr;
+    mgs_stager *s = new (std::nothrow) mgs_stager();
+    if (!s) return MGS_ERR_ARG;
+    s->h = h;
+    if (mgs_get_desc(h, &s->desc) != MGS_OK) {
+        delete s;
+        return MGS_ERR_ARG;
+    }
+    const int fl = fixed_len(s->desc.layout);
+    s->fixed = fl > 0;
+    s->cap = stage_bytes;
+    const uint64_t by_bytes = (uint64_t) stage_bytes / (uint64_t)(fl > 0 ? fl : 1);
+    s->max_rec = by_bytes < s->desc.max_records ? by_bytes : s->desc.max_records;
+    if (s->max_rec == 0) s->max_rec = 1;
+    memset(s->send_offset, 0, sizeof(s->send_offset));
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    const size_t image = (size_t) s->desc.nranks * (size_t) s->desc.buf_size;
+    hipError_t e = hipSetDevice(s->desc.device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(&s->h_stage, (size_t) stage_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&s->h_off, (s->max_rec + 1) * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&s->h_image, image, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&s->h_local, (size_t) stage_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&s->d_stage, (size_t) stage_bytes);
+    if (e == hipSuccess) e = hipMalloc(&s->d_off, (s->max_rec + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&s->d_image, image);
+    if (e == hipSuccess) e = hipMalloc(&s->d_local, (size_t) stage_bytes);
+    if (prev >= 0) (void) hipSetDevice(prev);
+    if (e != hipSuccess) {
+        g_stager_error = sfmt("mgs_stager_create: %s", hipGetErrorString(e));
+        mgs_stager_destroy(s);
+        return MGS_ERR_HIP;
+    }
+    s->h_off[0] = 0;
+    *out = s;
+    return MGS_OK;
+}
+
+// Append one pair in wire form.  Returns 0, or 1 when the staging buffer has
+// no room for it (nothing was staged: pack, then stage again).
+int mgs_stager_put(mgs_stager *s, const void *key, uint32_t klen, const void *val, uint32_t vlen)
+{
+    if (!s) return MGS_ERR_ARG;
+    const int64_t len = (int64_t) klen + (int64_t) vlen;
+    if (len <= 0 || len > s->cap) {
+        s->err = sfmt("record of %lld bytes cannot be staged (staging buffer %lld)",
+                      (long long) len, (long long) s->cap);
+        return MGS_ERR_RECORD_SIZE;
+    }
+    if (s->uploaded || s->nrec >= s->max_rec || s->used + len > s->cap) return 1;
+    if (klen) memcpy(s->h_stage + s->used, key, klen);
+    if (vlen) memcpy(s->h_stage + s->used + klen, val, vlen);
+    s->used += len;
+    s->nrec++;
+    s->h_off[s->nrec] = (uint32_t) s->used;
+    return MGS_OK;
+}
+
+uint64_t mgs_stager_pending(const mgs_stager *s) { return s ? s->nrec - s->cursor : 0; }
+
+// Pack the staged records that are not packed yet into the current round.
+// *drained = 1: every staged record was consumed and the staging buffer is
+// empty again.  *drained = 0: a partition is full -- the round must be
+// exchanged (mgs_stager_round_done) before the next call continues with the
+// record that did not fit (src/collectiveshuffler.h:148-160).
+// *local_records points at out->local_bytes bytes of wire-form records whose
+// destination is this rank, in emit order (valid until the next call).
+int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records, int *drained)
+{
+    if (!s || !out || !drained) return MGS_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    if (local_records) *local_records = s->h_local;
+    if (s->cursor >= s->nrec) {
+        for (int b = 0; b < s->desc.nranks; b++) out->send_offset[b] = s->send_offset[b];
+        out->next = s->cursor;
+        s->nrec = 0;
+        s->used = 0;
+        s->cursor = 0;
+        s->uploaded = false;
+        *drained = 1;
+        return MGS_OK;
+    }
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    struct Restore {
+        int p;
+        ~Restore() { if (p >= 0) (void) hipSetDevice(p); }
+    } restore{prev};
+    STG_HIP(s, hipSetDevice(s->desc.device));
+    if (!s->uploaded) {
+        STG_HIP(s, hipMemcpyAsync(s->d_stage, s->h_stage, (size_t) s->used, hipMemcpyHostToDevice, s->stream));
+        if (!s->fixed)
+            STG_HIP(s, hipMemcpyAsync(s->d_off, s->h_off, (s->nrec + 1) * sizeof(uint32_t),
+                                      hipMemcpyHostToDevice, s->stream));
+        s->uploaded = true;
+    }
+    int rc = mgs_pack_device(s->h, s->d_stage, s->fixed ? nullptr : s->d_off, s->nrec, s->cursor,
+                             s->send_offset, s->d_image, s->desc.rank >= 0 ? s->d_local : nullptr,
+                             s->cap, nullptr, MGS_ALGO_AUTO, s->stream, out);
+    if (rc != MGS_OK) {
+        s->err = mgs_last_error(s->h);
+        return rc;
+    }
+    if (out->local_bytes > 0) {
+        STG_HIP(s, hipMemcpyAsync(s->h_local, s->d_local, (size_t) out->local_bytes,
+                                  hipMemcpyDeviceToHost, s->stream));
+        STG_HIP(s, hipStreamSynchronize(s->stream));
+    }
+    if (out->next == s->cursor && out->local_records == 0) {
+        // nothing fitted although the round was handed over empty: cannot happen
+        // (a record larger than buf_size is reported by the pack call itself)
+        bool empty = true;
+        for (int b = 0; b < s->desc.nranks; b++) empty = empty && s->send_offset[b] == 0;
+        if (empty) {
+            s->err = "pack made no progress on an empty round";
+            return MGS_ERR_STATE;
+        }
+    }
+    for (int b = 0; b < s->desc.nranks; b++) s->send_offset[b] = out->send_offset[b];
+    s->cursor = out->next;
+    if (s->cursor >= s->nrec) {
+        s->nrec = 0;
+        s->used = 0;
+        s->cursor = 0;
+        s->uploaded = false;
+        *drained = 1;
+    }
+    else {
+        *drained = 0;
+    }
+    return MGS_OK;
+}
+
+// The round's send image.  Host view: the valid bytes of every partition are
+// copied to a pinned mirror with the reference's layout (partition d at
+// d*buf_size, src/collectiveshuffler.h:635) -- what MPI_Alltoallv reads.
+int mgs_stager_send_image_host(mgs_stager *s, const void **host_image, const int64_t **send_offset)
+{
+    if (!s || !host_image || !send_offset) return MGS_ERR_ARG;
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    (void) hipSetDevice(s->desc.device);
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < s->desc.nranks && e == hipSuccess; b++) {
+        if (s->send_offset[b] > 0)
+            e = hipMemcpyAsync(s->h_image + (size_t) b * s->desc.buf_size,
+                               s->d_image + (size_t) b * s->desc.buf_size,
+                               (size_t) s->send_offset[b], hipMemcpyDeviceToHost, s->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (prev >= 0) (void) hipSetDevice(prev);
+    if (e != hipSuccess) {
+        s->err = sfmt("send image copy failed: %s", hipGetErrorString(e));
+        return MGS_ERR_HIP;
+    }
+    *host_image = s->h_image;
+    *send_offset = s->send_offset;
+    return MGS_OK;
+}
+
+// Device view, for an exchange that reads GPU memory (RCCL, GPU-aware MPI).
+int mgs_stager_send_image_device(mgs_stager *s, void **d_image, const int64_t **send_offset)
+{
+    if (!s || !d_image || !send_offset) return MGS_ERR_ARG;
+    *d_image = s->d_image;
+    *send_offset = s->send_offset;
+    return MGS_OK;
+}
+
+// After the exchange: every partition is empty again (send_offset[i] = 0,
+// src/collectiveshuffler.h:657).
+int mgs_stager_round_done(mgs_stager *s)
+{
+    if (!s) return MGS_ERR_ARG;
+    memset(s->send_offset, 0, sizeof(s->send_offset));
+    return MGS_OK;
+}
+
+} // extern "C"

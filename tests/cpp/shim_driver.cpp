@@ -1,0 +1,192 @@
+// Test driver for include/mimir_gpu_shuffler.hpp: P ranks as P threads of one
+// process, every rank feeding its records one write(key*, val*) at a time into
+// a GpuShuffler<K,V> the way a Mimir map callback does, with an in-process
+// all-to-all standing in for MPI.  Dumps what each rank's `out` received.
+//
+//   shim_driver <kind> <P> <comm_bytes> <stage_bytes> <indir> <outdir> [keycount]
+//   kind: u64 | words | oct | join
+#include <pthread.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mimir_gpu_shuffler.hpp"
+
+using namespace mimir_gpu;
+
+struct Blob16 {
+    char b[16];
+};
+
+struct Shared {
+    int P;
+    pthread_barrier_t bar;
+    std::vector<int> counts;           // P x P
+    std::vector<const char *> sendbuf; // per rank
+    std::vector<const int *> scount, sdispl;
+};
+
+class ThreadExchange : public Exchange {
+  public:
+    ThreadExchange(Shared *s, int r) : s(s), r(r) {}
+    int rank() const { return r; }
+    int size() const { return s->P; }
+    void alltoall_int(const int *send, int *recv)
+    {
+        for (int d = 0; d < s->P; d++) s->counts[(size_t)(r * s->P + d)] = send[d];
+        pthread_barrier_wait(&s->bar);
+        for (int src = 0; src < s->P; src++) recv[src] = s->counts[(size_t)(src * s->P + r)];
+        pthread_barrier_wait(&s->bar);
+    }
+    void alltoallv_bytes(const char *sendbuf, const int *scount, const int *sdispl, char *recvbuf,
+                         const int *rcount, const int *rdispl)
+    {
+        s->sendbuf[(size_t) r] = sendbuf;
+        s->scount[(size_t) r] = scount;
+        s->sdispl[(size_t) r] = sdispl;
+        pthread_barrier_wait(&s->bar);
+        for (int src = 0; src < s->P; src++) {
+            if (rcount[src] != s->scount[(size_t) src][r]) {
+                fprintf(stderr, "count mismatch %d<-%d\n", r, src);
+                std::abort();
+            }
+            memcpy(recvbuf + rdispl[src], s->sendbuf[(size_t) src] + s->sdispl[(size_t) src][r],
+                   (size_t) rcount[src]);
+        }
+        pthread_barrier_wait(&s->bar);
+    }
+    void abort(int code) { std::_Exit(code); }
+
+  private:
+    Shared *s;
+    int r;
+};
+
+// Sink: re-serialises every pair it is handed, so the dump is wire form again.
+template <typename K, typename V>
+class DumpSink : public Writable<K, V> {
+  public:
+    DumpSink(int keycount, int valcount) : kc(keycount), vc(valcount), n(0) { off.push_back(0); }
+    int open() { return true; }
+    void close() {}
+    int seek(DB_POS) { return false; }
+    uint64_t get_record_count() { return n; }
+    int write(K *key, V *val)
+    {
+        std::vector<char> tmp;
+        const int kl = wire<K>::size(key, kc);
+        const char *kb = wire<K>::bytes(key, kc, tmp);
+        data.insert(data.end(), kb, kb + kl);
+        const int vl = wire<V>::size(val, vc);
+        const char *vb = wire<V>::bytes(val, vc, tmp);
+        if (vl) data.insert(data.end(), vb, vb + vl);
+        off.push_back((uint64_t) data.size());
+        n++;
+        return true;
+    }
+    std::vector<char> data;
+    std::vector<uint64_t> off;
+
+  private:
+    int kc, vc;
+    uint64_t n;
+};
+
+static std::vector<char> slurp(const std::string &p)
+{
+    std::ifstream f(p, std::ios::binary);
+    return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+template <typename K, typename V, typename Feed>
+static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const std::string &indir,
+                     const std::string &outdir, int keycount, Feed feed)
+{
+    std::vector<char> blob = slurp(indir + "/rank" + std::to_string(r) + ".blob");
+    std::vector<char> offb = slurp(indir + "/rank" + std::to_string(r) + ".off");
+    const uint64_t *off = reinterpret_cast<const uint64_t *>(offb.data());
+    const size_t n = offb.size() / 8 - 1;
+    ThreadExchange ex(sh, r);
+    DumpSink<K, V> sink(keycount, 1);
+    GpuShuffler<K, V> *c = new GpuShuffler<K, V>(&ex, &sink, NULL, keycount, 1, false, NULL, comm, 0);
+    c->open();
+    for (size_t i = 0; i < n; i++) feed(c, blob.data() + off[i], (int) (off[i + 1] - off[i]));
+    c->close();
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".out", std::ios::binary)
+        .write(sink.data.data(), (std::streamsize) sink.data.size());
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".outoff", std::ios::binary)
+        .write(reinterpret_cast<const char *>(sink.off.data()), (std::streamsize)(sink.off.size() * 8));
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".txt")
+        << c->get_record_count() << " " << c->get_shuffle_times() << "\n";
+    delete c;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 7) {
+        fprintf(stderr, "usage: %s kind P comm stage indir outdir [keycount]\n", argv[0]);
+        return 2;
+    }
+    const std::string kind = argv[1];
+    const int P = atoi(argv[2]);
+    const int64_t comm = atoll(argv[3]), stage = atoll(argv[4]);
+    const std::string indir = argv[5], outdir = argv[6];
+    const int keycount = argc > 7 ? atoi(argv[7]) : 1;
+    setenv("MIMIR_GPU_STAGE_SIZE", std::to_string(stage).c_str(), 1);
+    Shared sh;
+    sh.P = P;
+    pthread_barrier_init(&sh.bar, NULL, (unsigned) P);
+    sh.counts.assign((size_t)(P * P), 0);
+    sh.sendbuf.assign((size_t) P, NULL);
+    sh.scount.assign((size_t) P, NULL);
+    sh.sdispl.assign((size_t) P, NULL);
+    std::vector<std::thread> th;
+    for (int r = 0; r < P; r++) {
+        th.emplace_back([&, r]() {
+            if (kind == "u64") {
+                run_rank<uint64_t, uint64_t>(&sh, r, comm, stage, indir, outdir, 1,
+                    [](GpuShuffler<uint64_t, uint64_t> *c, char *rec, int) {
+                        uint64_t k, v;
+                        memcpy(&k, rec, 8);
+                        memcpy(&v, rec + 8, 8);
+                        c->write(&k, &v);
+                    });
+            }
+            else if (kind == "words") { // examples/wordcount.cpp:72-76
+                run_rank<char *, uint64_t>(&sh, r, comm, stage, indir, outdir, 1,
+                    [](GpuShuffler<char *, uint64_t> *c, char *rec, int len) {
+                        char *word = rec;
+                        uint64_t one;
+                        memcpy(&one, rec + len - 8, 8);
+                        c->write(&word, &one);
+                    });
+            }
+            else if (kind == "oct") { // examples/octree_clustering.cpp:226-235
+                run_rank<char, uint64_t>(&sh, r, comm, stage, indir, outdir, keycount,
+                    [keycount](GpuShuffler<char, uint64_t> *c, char *rec, int) {
+                        char key[16];
+                        memcpy(key, rec, (size_t) keycount);
+                        uint64_t count;
+                        memcpy(&count, rec + keycount, 8);
+                        c->write(key, &count);
+                    });
+            }
+            else { // join: examples/join.cpp:110-117
+                run_rank<char *, Blob16>(&sh, r, comm, stage, indir, outdir, 1,
+                    [](GpuShuffler<char *, Blob16> *c, char *rec, int len) {
+                        char *word = rec;
+                        Blob16 v;
+                        memcpy(&v, rec + len - 16, 16);
+                        c->write(&word, &v);
+                    });
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    return 0;
+}

@@ -1,0 +1,51 @@
+"""The C++ host shim (include/mimir_gpu_shuffler.hpp) end to end: a compiled
+driver runs P ranks as threads, each calling GpuShuffler<K,V>::write(key*,
+val*) once per record like a Mimir map callback; what every rank's `out`
+receives must equal the oracle simulation of the reference, order included."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from mimir_amd import capi, datagen
+from tests import refsim
+from tests.test_shuffle_gloo import make_stream
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "cpp", "shim_driver")
+
+
+@pytest.mark.parametrize("kind,P,keycount", [("u64", 2, 1), ("u64", 4, 1), ("words", 3, 1),
+                                             ("oct", 4, 11), ("join", 2, 1)])
+def test_cpp_shim_matches_reference(oracle, kind, P, keycount):
+    assert os.path.exists(DRIVER), "tests/cpp/shim_driver not built (__graft_entry__.build)"
+    counts = [0 if r == 1 else 5000 * (r + 1) + 11 for r in range(P)]
+    comm, stage = 16384, 40000
+    streams, lay = [], None
+    with tempfile.TemporaryDirectory() as d:
+        ind, outd = os.path.join(d, "in"), os.path.join(d, "out")
+        os.makedirs(ind)
+        os.makedirs(outd)
+        for r in range(P):
+            blob, offs, lay = make_stream(kind, r, counts[r])
+            if offs is None:
+                offs = datagen.fixed_offsets(counts[r], lay.fixed_len())
+            streams.append((blob, offs, counts[r]))
+            blob.tofile(os.path.join(ind, f"rank{r}.blob"))
+            np.asarray(offs, dtype=np.uint64).tofile(os.path.join(ind, f"rank{r}.off"))
+        subprocess.run([DRIVER, kind, str(P), str(comm), str(stage), ind, outd, str(keycount)],
+                       check=True, timeout=240)
+        buf_size = capi.geometry(comm, P)[0]
+        sinks, stats = refsim.simulate_shuffle(oracle, lay, streams, P, buf_size)
+        assert max(s["shuffle_times"] for s in stats) >= 3
+        for r in range(P):
+            data = np.fromfile(os.path.join(outd, f"rank{r}.out"), dtype=np.uint8).tobytes()
+            off = np.fromfile(os.path.join(outd, f"rank{r}.outoff"), dtype=np.uint64)
+            got = [data[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+            assert got == sinks[r], f"rank {r}: sink differs"
+            kv, times = open(os.path.join(outd, f"rank{r}.txt")).read().split()
+            assert int(kv) == stats[r]["kvcount"] and int(times) == stats[r]["shuffle_times"]
