@@ -26,27 +26,27 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak
+XGMI_LINK_GBS = 153.0       # one directed xGMI link
 ALGO_BYTES_PER_RECORD = 32  # read the 16-byte record once + write it once
 
 
-def cpu_baseline(n_target_seconds=12.0):
-    """Time the oracle's CollectiveShuffler::write loop on host cores (1)."""
+def cpu_baseline(records_dev, n_total, target_seconds=12.0):
+    """Time the oracle's CollectiveShuffler::write loop on one host core, on a
+    prefix of the very records the GPU packed."""
+    import ctypes as C
     import numpy as np
-    from mimir_amd import datagen
     from oracle import oracle as O
     orc = O.Oracle()
     lay = O.Layout.make(O.KEY_FIXED, 8, O.VAL_FIXED, 8)
     P = 8
 
     def run(n):
-        blob, _, _ = datagen.u64_records(n, seed=42)
+        blob = records_dev[:16 * n].cpu().numpy()
         buf = 16 * (n // P + n // 64 + 4096)
-        img = np.empty(P * buf, dtype=np.uint8)
+        img = np.zeros(P * buf, dtype=np.uint8)  # pages touched, like the reference's open()
         so = np.zeros(P, dtype=np.int64)
-        import ctypes as C
         lb, lr, pr = C.c_int64(), C.c_uint64(), C.c_uint64()
-        img[:] = 0  # touch the pages before timing, like the reference's open()
         t0 = time.perf_counter()
         nxt = orc.L.mo_pack_round(C.byref(lay), blob.ctypes.data, None, 16, n, 0, P, -1, buf,
                                   img.ctypes.data, so.ctypes.data, None, 0,
@@ -55,14 +55,30 @@ def cpu_baseline(n_target_seconds=12.0):
         assert nxt == n
         return dt
 
-    n0 = 1 << 22
+    n0 = min(1 << 22, n_total)
     dt0 = run(n0)
-    n = int(min(max(n0, n0 * n_target_seconds / max(dt0, 1e-6)), 1 << 29))
+    n = int(min(max(n0, n0 * target_seconds / max(dt0, 1e-6)), n_total))
     dt = run(n)
     return {"value": n / dt, "unit": "records/s", "cores": 1, "kind": "port",
             "GBps": n * ALGO_BYTES_PER_RECORD / dt / 1e9,
-            "sample": f"{n} <u64,u64> records (seed 42, same generator), P=8, "
-                      f"oracle/mimir_oracle.c mo_pack_round on one host core, {dt:.1f} s"}
+            "sample": f"first {n} of the benchmark's own <u64,u64> records, P=8, one round, "
+                      f"oracle/mimir_oracle.c mo_pack_round (C restatement of "
+                      f"CollectiveShuffler::write) on one host core, {dt:.1f} s"}
+
+
+def committed_traffic(kernel_substr, n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC passes (FETCH_SIZE doubled: gfx950 tallies 128-byte reads as 64; both
+    counters are in KiB), if such a profile exists for this kernel and size."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    if t.get("records") != n or kernel_substr not in t.get("kernel", ""):
+        return None
+    return t.get("hbm_bytes_per_launch")
 
 
 def main():
@@ -70,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--records", type=int, default=1_000_000_000)
+    ap.add_argument("--records", type=float, default=1e9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algo", default="auto", choices=["auto", "generic", "onesweep16"])
     args = ap.parse_args()
@@ -90,7 +106,7 @@ def main():
     dev = local_rank
     torch.cuda.set_device(dev)
 
-    n = args.records
+    n = int(args.records)
     P = 8 if not distributed else world
     self_rank = -1 if not distributed else rank
     algo = {"auto": capi.ALGO_AUTO, "generic": capi.ALGO_GENERIC,
@@ -106,15 +122,19 @@ def main():
     if distributed:
         from mimir_amd.exchange import exchange_round
 
-    kernel_ms = []
+    kernel_ms, pack_s, sent_max = [], [], 0
 
     def step():
+        nonlocal sent_max
+        t0 = time.perf_counter()
         r = pk.pack(records, n, image, local_out=local, algo=algo)
+        pack_s.append(time.perf_counter() - t0)
         if r.next != n:
             raise RuntimeError(f"round cut at {r.next}: partition capacity too small")
         kernel_ms.append(pk.last_kernel_ms())
         if distributed:
             exchange_round(image, r.send_offset, buf_size, recv)
+            sent_max = max(sent_max, int(r.send_offset.max()))
         return r
 
     def barrier():
@@ -125,10 +145,11 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
+    pack_s.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        last = step()
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
@@ -137,10 +158,12 @@ def main():
         dt = float(t.item())
 
     ms_per_step = dt / args.steps * 1e3
-    total_records = n * world
-    value = total_records * args.steps / dt
+    value = n * world * args.steps / dt
     k_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = n * ALGO_BYTES_PER_RECORD / (k_ms * 1e-3) / 1e9
+    kname = pk.tuning_name() if pk.last_algo() == "onesweep16" else "generic"
+    kernel = {"onesweep16": "k_onesweep16s" if kname.startswith("s") else "k_onesweep16*",
+              "generic": "k_gen_scatter"}[pk.last_algo()]
     out = {
         "metric": "device-resident KV records/s hash-partitioned & packed",
         "value": value,
@@ -152,25 +175,33 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 hash / u8 bytes",
+        "dtype": "u32",
         "data": "synthetic (seeded splitmix64 keys, value = record index)",
         "GBps_algorithmic": value * ALGO_BYTES_PER_RECORD / 1e9,
         "config": {
             "workload": ("configs[1]: fixed-width <uint64,uint64> records, hash-partition+pack into "
                          f"{P} destination partitions" + (", then RCCL all-to-all" if distributed else "")),
             "records_per_gpu": n, "record_bytes": 16, "partitions": P,
-            "local_bypass": distributed, "kernel": pk.last_algo(),
+            "local_bypass": distributed, "kernel_variant": kname,
             "rounds": "one round holds the batch (buf_size = share + 1/64 slack)",
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_onesweep16" if pk.last_algo() == "onesweep16" else "k_gen_scatter",
-                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_RECORD},
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": committed_traffic(kernel, n) if not distributed else None,
+                     "kernel": kernel, "kernel_ms": k_ms,
+                     "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_RECORD},
     }
+    if distributed:
+        pack_only = n * world / (sum(pack_s) / len(pack_s))
+        out["pack_only_records_per_s"] = pack_only
+        xfer_s = dt / args.steps - sum(pack_s) / len(pack_s)
+        out["exchange"] = {"hottest_pair_bytes": sent_max, "exchange_ms": xfer_s * 1e3,
+                           "xgmi_floor_ms": sent_max / (XGMI_LINK_GBS * 1e9) * 1e3,
+                           "frac_of_xgmi_pair_roofline": (sent_max / (XGMI_LINK_GBS * 1e9)) / max(xfer_s, 1e-9)}
     if rank == 0 and not distributed and not args.no_cpu_baseline:
-        del records, image
+        del image
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(records, n)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -231,6 +231,7 @@ int mgs_last_kernel_ms(mgs_handle *h, float *ms);
  * records from d_in to d_out with the same tile loop and nothing else, and
  * reports the device time: what a perfect partitioner could reach here. */
 int mgs_set_tuning(mgs_handle *h, int variant);
+int mgs_get_tuning(const mgs_handle *h);
 int mgs_debug_stats(mgs_handle *h, uint64_t out[8]); /* counters of a "-stats" variant */
 const char *mgs_tuning_name(int variant);
 int mgs_copy_calibration(mgs_handle *h, const void *d_in, void *d_out,

@@ -77,6 +77,7 @@ SYMBOLS = {
     "mgs_pack_result": (C.c_int, [_VP, C.POINTER(Round)]),
     "mgs_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "mgs_set_tuning": (C.c_int, [_VP, C.c_int]),
+    "mgs_get_tuning": (C.c_int, [_VP]),
     "mgs_tuning_name": (C.c_char_p, [C.c_int]),
     "mgs_debug_stats": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "mgs_copy_calibration": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP,

@@ -561,6 +561,8 @@ int mgs_debug_stats(mgs_handle *h, uint64_t out[8])
     return MGS_OK;
 }
 
+int mgs_get_tuning(const mgs_handle *h) { return h ? h->os_variant : -1; }
+
 const char *mgs_tuning_name(int variant)
 {
     return (variant >= 0 && variant < kNumOsVariants) ? kOsVariants[variant].name : NULL;

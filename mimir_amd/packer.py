@@ -78,6 +78,9 @@ class DevicePacker:
         self._check(self.lib.mgs_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def tuning_name(self):
+        return self.lib.mgs_tuning_name(self.lib.mgs_get_tuning(self.h)).decode()
+
     def set_tuning(self, variant):
         self._check(self.lib.mgs_set_tuning(self.h, variant))
 
