@@ -162,7 +162,8 @@ def main():
     k_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = n * ALGO_BYTES_PER_RECORD / (k_ms * 1e-3) / 1e9
     kname = pk.tuning_name() if pk.last_algo() == "onesweep16" else "generic"
-    kernel = {"onesweep16": "k_onesweep16s" if kname.startswith("s") else "k_onesweep16*",
+    # variant names start with the kernel family's letter (t = the plain kernel)
+    kernel = {"onesweep16": "k_onesweep16" + ("<" if kname.startswith("t") else kname[:1]),
               "generic": "k_gen_scatter"}[pk.last_algo()]
     out = {
         "metric": "device-resident KV records/s hash-partitioned & packed",

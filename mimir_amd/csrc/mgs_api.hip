@@ -15,6 +15,8 @@
 #include "mgs_onesweep16s.h"
 #include "mgs_onesweep16d.h"
 #include "mgs_onesweep16e.h"
+#include "mgs_onesweep16p.h"
+#include "mgs_onesweep16f.h"
 
 using namespace mgs;
 
@@ -70,6 +72,12 @@ struct OsVariant {
     {name, T, I, B, T * I, k_onesweep16d<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
 #define OSE(name, T, I, V, B) \
     {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16e<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
+#define OSSL(name, T, I, V, B, L) \
+    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16s<T, I, V, (B * (T / 64) + 3) / 4, L>, k_copy16<T, I, 0>}
+#define OSP(name, T, I, V, B, L) \
+    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16p<T, I, V, (B * (T / 64) + 3) / 4, L>, k_copy16<T, I, 0>}
+#define OSF(name, T, I, V, B, L) \
+    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16f<T, I, V, (B * (T / 64) + 3) / 4, L>, k_copy16<T, I, 0>}
 static const OsVariant kOsVariants[] = {
     OSV("t512x8", 512, 8, 0, 2),
     OSV("t512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
@@ -119,10 +127,44 @@ static const OsVariant kOsVariants[] = {
     OSS("s512x8-early-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2),
     OSS("s1024x8-early", 1024, 8, OSV_EARLY_AGG, 1),                // 46
     OSS("s1024x8-early-stats", 1024, 8, OSV_EARLY_AGG | OSV_STATS, 1),
+    OSS("s512x8-late", 512, 8, OSV_LATE_TICKET, 2),                 // 48
+    OSS("s512x8-late-stats", 512, 8, OSV_LATE_TICKET | OSV_STATS, 2),
+    OSS("s1024x8-late", 1024, 8, OSV_LATE_TICKET, 1),               // 50
+    OSS("s512x8-late-early", 512, 8, OSV_LATE_TICKET | OSV_EARLY_AGG, 2),
+    OSSL("s512x8-w16", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST, 2, 16),                  // 52
+    OSSL("s512x8-w16-stats", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST | OSV_STATS, 2, 16),
+    OSSL("s512x8-w24", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST, 2, 24),                  // 54
+    OSSL("s512x8-w32", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST, 2, 32),
+    OSSL("s1024x8-w16", 1024, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST, 1, 16),                // 56
+    OSSL("s512x8-w32-stats", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST | OSV_STATS, 2, 32),
+    OSP("p512x8-w8", 512, 8, 0, 2, 8),                 // 58
+    OSP("p512x8-w16", 512, 8, 0, 2, 16),
+    OSP("p512x8-w24", 512, 8, 0, 2, 24),               // 60
+    OSP("p512x8-w32", 512, 8, 0, 2, 32),
+    OSP("p512x8-w16-stats", 512, 8, OSV_STATS, 2, 16), // 62
+    OSP("p512x8-w32-stats", 512, 8, OSV_STATS, 2, 32),
+    OSP("p1024x8-w16", 1024, 8, 0, 1, 16),             // 64
+    OSP("p512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8),
+    OSF("f512x8-w16", 512, 8, 0, 2, 16),                 // 66
+    OSF("f512x8-w8", 512, 8, 0, 2, 8),
+    OSF("f512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8), // 68
+    OSF("f512x8-w16-stats", 512, 8, OSV_STATS, 2, 16),
+    OSF("f1024x8-w16", 1024, 8, 0, 1, 16),               // 70
+    OSF("f1024x8-fakechain", 1024, 8, OSV_FAKE_CHAIN, 1, 8),
+    OSF("f512x8-w16-d1", 512, 8, 1 << OSV_DELAY_SHIFT, 2, 16), // 72
+    OSF("f512x8-w16-d2", 512, 8, 2 << OSV_DELAY_SHIFT, 2, 16),
+    OSF("f512x8-w16-d3", 512, 8, 3 << OSV_DELAY_SHIFT, 2, 16), // 74
+    OSF("f512x8-w16-d2-stats", 512, 8, (2 << OSV_DELAY_SHIFT) | OSV_STATS, 2, 16),
+    OSF("f512x8-w24-d2", 512, 8, 2 << OSV_DELAY_SHIFT, 2, 24), // 76
+    OSF("f512x8-w16-ea", 512, 8, OSV_EARLY_AGG, 2, 16),        // 77
+    OSF("f512x8-w16-ea-d1", 512, 8, OSV_EARLY_AGG | (1 << OSV_DELAY_SHIFT), 2, 16),
+    OSF("f512x8-w16-ea-d3", 512, 8, OSV_EARLY_AGG | (3 << OSV_DELAY_SHIFT), 2, 16), // 79
+    OSF("f512x8-w16-ea-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2, 16),
+    OSF("f512x8-w8-ea", 512, 8, OSV_EARLY_AGG, 2, 8),         // 81
 };
 constexpr int kNumOsVariants = (int) (sizeof(kOsVariants) / sizeof(kOsVariants[0]));
 constexpr int kOsMinTile = 2048;
-constexpr int kDefaultOsVariant = 13; // "s512x8": fastest measured on MI355X (tools/tune_onesweep.py)
+constexpr int kDefaultOsVariant = 59; // "p512x8-w16": fastest measured on MI355X (tools/tune_onesweep.py)
 
 struct mgs_handle {
     mgs_desc desc;

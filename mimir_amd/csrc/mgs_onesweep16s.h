@@ -51,8 +51,25 @@ struct OssGeom {
 // initial fill.  Lane = (j, b): predecessor slot j of a load, destination b;
 // one poll fetches OS_LOOK loads x (64 >> nbits_pad) predecessors and every
 // decision is wave-uniform, so the walk is a scalar loop.
+struct OsWalkStats { // per scan wave, flushed to Ctrl::stats once at the end of the kernel
+    unsigned long long tiles = 0, polls = 0, idle = 0, depth = 0, cycles = 0;
+    unsigned long long max_depth = 0, max_cycles = 0, max_polls = 0;
+    __device__ void flush(Ctrl *ctrl) const
+    {
+        atomicAdd(&ctrl->head.stats[0], tiles);
+        atomicAdd(&ctrl->head.stats[1], polls);
+        atomicAdd(&ctrl->head.stats[2], idle);
+        atomicAdd(&ctrl->head.stats[3], depth);
+        atomicAdd(&ctrl->head.stats[4], cycles);
+        atomicMax(&ctrl->head.stats[5], max_depth);
+        atomicMax(&ctrl->head.stats[6], max_cycles);
+        atomicMax(&ctrl->head.stats[7], max_polls);
+    }
+};
+
 template <int VAR, int LOOKMAX = OS_LOOK>
-__device__ __forceinline__ unsigned long long os_chain_walk(const OsParams &p, uint32_t tile, int lane)
+__device__ __forceinline__ unsigned long long os_chain_walk(const OsParams &p, uint32_t tile, int lane,
+                                                            OsWalkStats *ws = nullptr)
 {
     const uint32_t P = p.P;
     const uint32_t Pp = 1u << p.nbits_pad;   // P rounded up to a power of two
@@ -68,7 +85,7 @@ __device__ __forceinline__ unsigned long long os_chain_walk(const OsParams &p, u
     uint32_t st_polls = 0, st_idle = 0;
     unsigned long long st_t0 = 0;
     if (VAR & OSV_STATS) st_t0 = __builtin_readcyclecounter();
-    int nq = OS_LOOK; // loads in this poll; widened once a whole window was aggregates only
+    int nq = (LOOKMAX < OS_LOOK0) ? LOOKMAX : ((VAR & OSV_WIDE_FIRST) ? LOOKMAX : OS_LOOK); // loads in this poll
     while (!done) {
         unsigned long long v[LOOKMAX];
 #pragma unroll
@@ -113,7 +130,7 @@ __device__ __forceinline__ unsigned long long os_chain_walk(const OsParams &p, u
             }
         }
         look -= consumed;
-        nq = (!stop) ? LOOKMAX : OS_LOOK;
+        nq = (!stop || (VAR & OSV_WIDE_FIRST)) ? LOOKMAX : OS_LOOK;
         if (VAR & OSV_STATS) {
             st_polls++;
             if (consumed == 0 && !done) st_idle++;
@@ -139,17 +156,17 @@ __device__ __forceinline__ unsigned long long os_chain_walk(const OsParams &p, u
             }
         }
     }
-    if ((VAR & OSV_STATS) && lane == 0) {
+    if ((VAR & OSV_STATS) && ws) {
         const unsigned long long dt = __builtin_readcyclecounter() - st_t0;
         const unsigned long long depth = (unsigned long long) ((int64_t) tile - 1 - look);
-        atomicAdd(&p.ctrl->head.stats[0], 1ull);                          // tiles that scanned
-        atomicAdd(&p.ctrl->head.stats[1], (unsigned long long) st_polls); // polls
-        atomicAdd(&p.ctrl->head.stats[2], (unsigned long long) st_idle);  // polls with nothing new
-        atomicAdd(&p.ctrl->head.stats[3], depth);                         // predecessors summed
-        atomicAdd(&p.ctrl->head.stats[4], dt);                            // cycles inside the walk
-        atomicMax(&p.ctrl->head.stats[5], depth);
-        atomicMax(&p.ctrl->head.stats[6], dt);
-        atomicMax(&p.ctrl->head.stats[7], (unsigned long long) st_polls);
+        ws->tiles += 1;
+        ws->polls += st_polls;
+        ws->idle += st_idle;
+        ws->depth += depth;
+        ws->cycles += dt;
+        ws->max_depth = depth > ws->max_depth ? depth : ws->max_depth;
+        ws->max_cycles = dt > ws->max_cycles ? dt : ws->max_cycles;
+        ws->max_polls = st_polls > ws->max_polls ? st_polls : ws->max_polls;
     }
     // fold the per-slot partial sums: lanes with equal b, strides Pp..32
     for (uint32_t o = Pp; o < 64u; o <<= 1) {
@@ -160,7 +177,7 @@ __device__ __forceinline__ unsigned long long os_chain_walk(const OsParams &p, u
     return acc;
 }
 
-template <int THREADS, int ITEMS, int VAR, int MINW>
+template <int THREADS, int ITEMS, int VAR, int MINW, int LOOK = OS_LOOK>
 __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
 {
     using G = OssGeom<THREADS, ITEMS>;
@@ -198,6 +215,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
     uint4 r[ITEMS];
     if (!scanner && tile < p.ntiles) os_load_tile<ITEMS, VAR>(p, tile, TILE, w, lane, r);
     int par = 0;
+    OsWalkStats ws;
 
     // Store the LDS image of the previous tile: consecutive lanes write
     // consecutive 16-byte slots of one partition run.
@@ -243,7 +261,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
         uint32_t *wc = wcnt + par * (WORKERS * OS_MAXP);
         uint32_t meta[ITEMS]; // dest | rank<<8 | count<<16 | valid<<31
         if (scanner) {
-            if (lane == 0) misc[1] = atomicAdd(&p.ctrl->head.ticket, 1u);
+            if (!(VAR & OSV_LATE_TICKET)) {
+                if (lane == 0) misc[1] = atomicAdd(&p.ctrl->head.ticket, 1u);
+            }
         }
         else {
             // ---- hash, destination, rank within row ---------------------------
@@ -282,7 +302,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
             }
         }
         __syncthreads(); // A: counts(tile) complete; image(prev) and position(prev) ready
-        const uint32_t next = misc[1];
+        uint32_t next = 0;
+        if (!(VAR & OSV_LATE_TICKET)) next = misc[1];
 
         // ---- per-destination totals (lane = destination) ----------------------
         uint32_t tot = 0, below = 0;
@@ -310,6 +331,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
             for (int j = lane; j < WORKERS * OS_MAXP; j += 64)
                 wcnt[(par ^ 1) * (WORKERS * OS_MAXP) + j] = 0;
             if (lane == 0) misc[2 + (par ^ 1)] = 0;
+            // Drawing the next tile only now keeps the time between a tile's ticket and
+            // the publication of its counts short (less skew between neighbouring tiles).
+            if ((VAR & OSV_LATE_TICKET) && lane == 0) misc[1] = atomicAdd(&p.ctrl->head.ticket, 1u);
         }
         else {
             const uint32_t incl = wave_incl_scan_u32(tot, lane);
@@ -322,12 +346,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
             if (prev != 0xFFFFFFFFu) store_image(prev, par ^ 1);
         }
         __syncthreads(); // B: every slot of image(prev) has been read, the image is free
+        if (VAR & OSV_LATE_TICKET) next = misc[1];
 
         if (scanner) {
             if (tile != 0) {
                 unsigned long long acc;
                 if (VAR & OSV_FAKE_CHAIN) acc = (unsigned long long) tile * (TILE / P);
-                else acc = os_chain_walk<VAR>(p, tile, lane);
+                else acc = os_chain_walk<VAR, LOOK>(p, tile, lane, &ws);
                 if ((uint32_t) lane < P) {
                     if (!(VAR & OSV_FAKE_CHAIN))
                         os_store_status(p.status + (uint64_t) tile * P + lane,
@@ -358,6 +383,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16s(OsParams p)
     }
     __syncthreads(); // image(prev) and position(prev) ready
     if (!scanner && prev != 0xFFFFFFFFu) store_image(prev, par ^ 1);
+    if ((VAR & OSV_STATS) && scanner && lane == 0) ws.flush(p.ctrl);
 }
 
 } // namespace mgs
