@@ -17,6 +17,7 @@
 #include "mgs_onesweep16e.h"
 #include "mgs_onesweep16p.h"
 #include "mgs_onesweep16f.h"
+#include "mgs_onesweep16w.h"
 
 using namespace mgs;
 
@@ -56,115 +57,63 @@ int fixed_record_bytes(const mgs_layout &l)
 
 } // namespace
 
-// Instantiations of the one-sweep kernel.  Entry 0 is what production calls
-// run; the rest are there to be timed against it (mgs_set_tuning).
+// Instantiations of the one-sweep kernel.  kDefaultOsVariant is what production
+// calls run; the rest are there to be timed against it (mgs_set_tuning,
+// tools/tune_onesweep.py): each prices one design decision on the hardware.
+typedef void (*OsKernel)(OsParams);
 struct OsVariant {
     const char *name;
     int threads, items, blocks_per_cu, tile;
-    void (*kernel)(OsParams);
-    void (*copy)(const uint4 *, uint4 *, uint64_t, uint32_t, uint32_t *);
+    bool agg16;         // uses the 16-bit count array of the windowed scan
+    OsKernel kernel[7]; // by number of destination bits (1..6); [0] unused
 };
-#define OSV(name, T, I, V, B) \
-    {name, T, I, B, T * I, k_onesweep16<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
+#define MINW_(T, B) ((B * (T / 64) + 3) / 4)
+#define SAME7(k) {k, k, k, k, k, k, k}
+#define OSV(name, T, I, V, B) {name, T, I, B, T * I, false, SAME7((k_onesweep16<T, I, V, MINW_(T, B)>))}
 #define OSS(name, T, I, V, B) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16s<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
-#define OSD(name, T, I, V, B) \
-    {name, T, I, B, T * I, k_onesweep16d<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
+    {name, T, I, B, (T / 64 - 1) * 64 * I, false, SAME7((k_onesweep16s<T, I, V, MINW_(T, B)>))}
+#define OSD(name, T, I, V, B) {name, T, I, B, T * I, false, SAME7((k_onesweep16d<T, I, V, MINW_(T, B)>))}
 #define OSE(name, T, I, V, B) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16e<T, I, V, (B * (T / 64) + 3) / 4>, k_copy16<T, I, 0>}
-#define OSSL(name, T, I, V, B, L) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16s<T, I, V, (B * (T / 64) + 3) / 4, L>, k_copy16<T, I, 0>}
+    {name, T, I, B, (T / 64 - 1) * 64 * I, false, SAME7((k_onesweep16e<T, I, V, MINW_(T, B)>))}
 #define OSP(name, T, I, V, B, L) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16p<T, I, V, (B * (T / 64) + 3) / 4, L>, k_copy16<T, I, 0>}
+    {name, T, I, B, (T / 64 - 1) * 64 * I, false, SAME7((k_onesweep16p<T, I, V, MINW_(T, B), L>))}
 #define OSF(name, T, I, V, B, L) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, k_onesweep16f<T, I, V, (B * (T / 64) + 3) / 4, L>, k_copy16<T, I, 0>}
+    {name, T, I, B, (T / 64 - 1) * 64 * I, ((V) & OSV_WINDOW) != 0, SAME7((k_onesweep16f<T, I, V, MINW_(T, B), L>))}
+#define OSQ(name, T, I, V, B, L)                                                                    \
+    {name, T, I, B, (T / 64 - 1) * 64 * I, true,                                                    \
+     {nullptr, k_onesweep16q<T, I, V, MINW_(T, B), L, 1>, k_onesweep16q<T, I, V, MINW_(T, B), L, 2>, \
+      k_onesweep16q<T, I, V, MINW_(T, B), L, 3>, k_onesweep16q<T, I, V, MINW_(T, B), L, 4>,          \
+      k_onesweep16q<T, I, V, MINW_(T, B), L, 5>, k_onesweep16q<T, I, V, MINW_(T, B), L, 6>}}
 static const OsVariant kOsVariants[] = {
-    OSV("t512x8", 512, 8, 0, 2),
+    OSQ("q512x8-w8", 512, 8, OSV_EARLY_AGG, 2, 8),                      // 0: production
+    OSQ("q512x8-w8-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2, 8),
+    OSQ("q512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8),              // 2
+    OSQ("q512x8-w4", 512, 8, OSV_EARLY_AGG, 2, 4),
+    OSQ("q512x8-w12", 512, 8, OSV_EARLY_AGG, 2, 12),                    // 4
+    OSQ("q512x8-w12-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2, 12),
+    OSQ("q512x8-w8-late", 512, 8, 0, 2, 8),                             // 6: counts published by the scan wave
+    OSQ("q512x8-w8-late-stats", 512, 8, OSV_STATS, 2, 8),
+    OSV("t512x8", 512, 8, 0, 2),                            // 8: LDS image, every wave works, wave 0 walks
     OSV("t512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
-    OSV("t512x8-noprefetch", 512, 8, OSV_NO_PREFETCH, 2),
-    OSV("t512x8-nt", 512, 8, OSV_NT_LOAD | OSV_NT_STORE, 2),
-    OSV("t256x8", 256, 8, 0, 4),
-    OSV("t256x16", 256, 16, 0, 2),
-    OSV("t1024x8", 1024, 8, 0, 1),
-    OSV("t1024x4", 1024, 4, 0, 2),
-    OSV("t512x4", 512, 4, 0, 4),
-    OSV("t512x8-ntstore", 512, 8, OSV_NT_STORE, 2),
-    OSV("t512x8-ntload", 512, 8, OSV_NT_LOAD, 2),
-    OSV("t512x8-stats", 512, 8, OSV_STATS, 2),
-    OSV("t1024x8-stats", 1024, 8, OSV_STATS, 1),
-    OSS("s512x8", 512, 8, 0, 2),
-    OSS("s512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
+    OSV("t512x8-stats", 512, 8, OSV_STATS, 2),              // 10
+    OSS("s512x8", 512, 8, 0, 2),                            // scan wave, one loop
+    OSS("s512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),     // 12
     OSS("s512x8-stats", 512, 8, OSV_STATS, 2),
-    OSS("s1024x8", 1024, 8, 0, 1),
-    OSS("s1024x8-stats", 1024, 8, OSV_STATS, 1),
-    OSS("s576x8", 576, 8, 0, 2),
-    OSS("s320x8", 320, 8, 0, 4),
-    OSS("s512x8-nt", 512, 8, OSV_NT_LOAD | OSV_NT_STORE, 2),
-    OSS("s1024x8-nt", 1024, 8, OSV_NT_LOAD | OSV_NT_STORE, 1),
-    OSS("s1024x4", 1024, 4, 0, 2),
-    OSD("d256x8", 256, 8, 0, 4),             // 23
-    OSD("d256x8-fakechain", 256, 8, OSV_FAKE_CHAIN, 4),
-    OSD("d512x8", 512, 8, 0, 2),             // 25
-    OSD("d512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
-    OSD("d1024x8", 1024, 8, 0, 1),           // 27
-    OSD("d256x8-b5", 256, 8, 0, 5),
-    OSD("d256x8-b6", 256, 8, 0, 6),          // 29
-    OSD("d256x4-b8", 256, 4, 0, 8),
-    OSD("d512x8-b3", 512, 8, 0, 3),          // 31
-    OSD("d256x16", 256, 16, 0, 2),
-    OSD("d512x4-b4", 512, 4, 0, 4),          // 33
-    OSE("e512x8", 512, 8, 0, 2),             // 34
-    OSE("e512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
-    OSE("e512x8-stats", 512, 8, OSV_STATS, 2), // 36
-    OSE("e1024x8", 1024, 8, 0, 1),
-    OSE("e1024x4", 1024, 4, 0, 1),           // 38
-    OSE("e512x4-b3", 512, 4, 0, 3),
-    OSE("e512x4-b2", 512, 4, 0, 2),          // 40
-    OSE("e256x8-b4", 256, 8, 0, 4),
-    OSE("e1024x8-stats", 1024, 8, OSV_STATS, 1), // 42
-    OSE("e768x8", 768, 8, 0, 1),
-    OSS("s512x8-early", 512, 8, OSV_EARLY_AGG, 2),                  // 44
-    OSS("s512x8-early-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2),
-    OSS("s1024x8-early", 1024, 8, OSV_EARLY_AGG, 1),                // 46
-    OSS("s1024x8-early-stats", 1024, 8, OSV_EARLY_AGG | OSV_STATS, 1),
-    OSS("s512x8-late", 512, 8, OSV_LATE_TICKET, 2),                 // 48
-    OSS("s512x8-late-stats", 512, 8, OSV_LATE_TICKET | OSV_STATS, 2),
-    OSS("s1024x8-late", 1024, 8, OSV_LATE_TICKET, 1),               // 50
-    OSS("s512x8-late-early", 512, 8, OSV_LATE_TICKET | OSV_EARLY_AGG, 2),
-    OSSL("s512x8-w16", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST, 2, 16),                  // 52
-    OSSL("s512x8-w16-stats", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST | OSV_STATS, 2, 16),
-    OSSL("s512x8-w24", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST, 2, 24),                  // 54
-    OSSL("s512x8-w32", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST, 2, 32),
-    OSSL("s1024x8-w16", 1024, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST, 1, 16),                // 56
-    OSSL("s512x8-w32-stats", 512, 8, OSV_LATE_TICKET | OSV_WIDE_FIRST | OSV_STATS, 2, 32),
-    OSP("p512x8-w8", 512, 8, 0, 2, 8),                 // 58
-    OSP("p512x8-w16", 512, 8, 0, 2, 16),
-    OSP("p512x8-w24", 512, 8, 0, 2, 24),               // 60
-    OSP("p512x8-w32", 512, 8, 0, 2, 32),
-    OSP("p512x8-w16-stats", 512, 8, OSV_STATS, 2, 16), // 62
-    OSP("p512x8-w32-stats", 512, 8, OSV_STATS, 2, 32),
-    OSP("p1024x8-w16", 1024, 8, 0, 1, 16),             // 64
-    OSP("p512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8),
-    OSF("f512x8-w16", 512, 8, 0, 2, 16),                 // 66
-    OSF("f512x8-w8", 512, 8, 0, 2, 8),
-    OSF("f512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8), // 68
+    OSP("p512x8-w16", 512, 8, 0, 2, 16),                    // 14: scan wave, split loops, 128-tile walk
+    OSP("p512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 16),
+    OSP("p512x8-w16-stats", 512, 8, OSV_STATS, 2, 16),      // 16
+    OSD("d512x8", 512, 8, 0, 2),                            // direct scatter from registers
+    OSD("d512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),     // 18
+    OSE("e512x8", 512, 8, 0, 2),                            // direct scatter, two register sets
+    OSE("e512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),     // 20
+    OSF("f512x8-w16-d3", 512, 8, 3 << OSV_DELAY_SHIFT, 2, 16), // direct scatter, tile parked in LDS
+    OSF("f512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8),  // 22
     OSF("f512x8-w16-stats", 512, 8, OSV_STATS, 2, 16),
-    OSF("f1024x8-w16", 1024, 8, 0, 1, 16),               // 70
-    OSF("f1024x8-fakechain", 1024, 8, OSV_FAKE_CHAIN, 1, 8),
-    OSF("f512x8-w16-d1", 512, 8, 1 << OSV_DELAY_SHIFT, 2, 16), // 72
-    OSF("f512x8-w16-d2", 512, 8, 2 << OSV_DELAY_SHIFT, 2, 16),
-    OSF("f512x8-w16-d3", 512, 8, 3 << OSV_DELAY_SHIFT, 2, 16), // 74
-    OSF("f512x8-w16-d2-stats", 512, 8, (2 << OSV_DELAY_SHIFT) | OSV_STATS, 2, 16),
-    OSF("f512x8-w24-d2", 512, 8, 2 << OSV_DELAY_SHIFT, 2, 24), // 76
-    OSF("f512x8-w16-ea", 512, 8, OSV_EARLY_AGG, 2, 16),        // 77
-    OSF("f512x8-w16-ea-d1", 512, 8, OSV_EARLY_AGG | (1 << OSV_DELAY_SHIFT), 2, 16),
-    OSF("f512x8-w16-ea-d3", 512, 8, OSV_EARLY_AGG | (3 << OSV_DELAY_SHIFT), 2, 16), // 79
-    OSF("f512x8-w16-ea-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2, 16),
-    OSF("f512x8-w8-ea", 512, 8, OSV_EARLY_AGG, 2, 8),         // 81
+    OSF("g512x8-w12-d3", 512, 8, OSV_WINDOW | (3 << OSV_DELAY_SHIFT), 2, 12), // 24: f with the windowed scan
+    OSF("g512x8-w12-d3-stats", 512, 8, OSV_WINDOW | OSV_STATS | (3 << OSV_DELAY_SHIFT), 2, 12),
 };
 constexpr int kNumOsVariants = (int) (sizeof(kOsVariants) / sizeof(kOsVariants[0]));
-constexpr int kOsMinTile = 2048;
-constexpr int kDefaultOsVariant = 59; // "p512x8-w16": fastest measured on MI355X (tools/tune_onesweep.py)
+constexpr int kDefaultOsVariant = 0;
 
 struct mgs_handle {
     mgs_desc desc;
@@ -184,6 +133,7 @@ struct mgs_handle {
     uint8_t *d_dest = nullptr;
     // one-sweep path scratch
     unsigned long long *d_status = nullptr;
+    unsigned long long *d_agg16 = nullptr;
     // call in flight
     bool pending = false;
     hipStream_t pending_stream = nullptr;
@@ -278,6 +228,7 @@ void mgs_destroy(mgs_handle *h)
         if (h->d_tile_base) (void) hipFree(h->d_tile_base);
         if (h->d_dest) (void) hipFree(h->d_dest);
         if (h->d_status) (void) hipFree(h->d_status);
+        if (h->d_agg16) (void) hipFree(h->d_agg16);
         if (h->h_head) (void) hipHostFree(h->h_head);
         if (h->h_ctrl) (void) hipHostFree(h->h_ctrl);
         if (h->ev0) (void) hipEventDestroy(h->ev0);
@@ -367,11 +318,14 @@ static int ensure_generic_scratch(mgs_handle *h, bool need_dest)
 
 static int ensure_onesweep_scratch(mgs_handle *h)
 {
-    int min_tile = kOsMinTile;
+    int min_tile = kOsVariants[0].tile; // sized for any variant mgs_set_tuning may select
     for (int v = 0; v < kNumOsVariants; v++) min_tile = std::min(min_tile, kOsVariants[v].tile);
     const uint64_t tiles = (h->desc.max_records + min_tile - 1) / min_tile;
     if (!h->d_status)
         MGS_HIP(h, hipMalloc(&h->d_status, tiles * (uint64_t) h->desc.nranks * sizeof(unsigned long long)));
+    if (!h->d_agg16) // (1 << lpt_log) <= 2 * ceil(nranks / 4) words per tile
+        MGS_HIP(h, hipMalloc(&h->d_agg16,
+                             tiles * (uint64_t) ((h->desc.nranks + 3) / 4 * 2) * sizeof(unsigned long long)));
     return MGS_OK;
 }
 
@@ -481,6 +435,10 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         p.P = (uint32_t) P;
         p.self = D.rank;
         p.klen = (uint32_t) D.layout.key_bytes;
+        for (int w = 0; w < 4; w++) {
+            const int kb = std::min(4, std::max(0, D.layout.key_bytes - 4 * w));
+            p.kmask[w] = kb == 4 ? 0xFFFFFFFFu : ((1u << (8 * kb)) - 1u);
+        }
         p.nbits = 1;
         while ((1u << p.nbits) < (uint32_t) P) p.nbits++;
         p.nbits_pad = (P == 1) ? 0 : p.nbits;
@@ -489,12 +447,16 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         p.tile_records = (uint32_t) V.tile;
         p.ntiles = (uint32_t)((n + p.tile_records - 1) / p.tile_records);
         p.status = h->d_status;
+        p.agg16 = h->d_agg16;
+        p.lpt_log = p.nbits_pad > 2 ? p.nbits_pad - 2 : 0;
         p.dest_out = d_dest_out;
         p.ctrl = h->d_ctrl;
         MGS_HIP(h, hipMemsetAsync(h->d_status, 0, (size_t) p.ntiles * P * sizeof(unsigned long long), stream));
+        if (V.agg16)
+            MGS_HIP(h, hipMemsetAsync(h->d_agg16, 0, ((size_t) p.ntiles << p.lpt_log) * sizeof(unsigned long long), stream));
         const uint32_t grid = std::min<uint32_t>(p.ntiles, (uint32_t)(h->num_cus * V.blocks_per_cu));
         MGS_HIP(h, hipEventRecord(h->ev0, stream));
-        hipLaunchKernelGGL(V.kernel, dim3(grid), dim3(V.threads), 0, stream, p);
+        hipLaunchKernelGGL(V.kernel[p.nbits], dim3(grid), dim3(V.threads), 0, stream, p);
         MGS_HIP(h, hipEventRecord(h->ev1, stream));
         hipLaunchKernelGGL(k_os_finalize, dim3(1), dim3(64), 0, stream, p);
         h->last_algo = "onesweep16";
@@ -616,14 +578,15 @@ int mgs_copy_calibration(mgs_handle *h, const void *d_in, void *d_out, uint64_t 
     if (!h || !d_in || !d_out || !ms || n_records == 0) return MGS_ERR_ARG;
     DeviceGuard g(h->desc.device);
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
-    const OsVariant &V = kOsVariants[h->os_variant];
-    const uint32_t tile = (uint32_t)(V.threads * V.items);
+    // a plain ticketed copy with the production kernel's shape: 512 threads, 8 records each
+    constexpr int T = 512, I = 8;
+    const uint32_t tile = (uint32_t)(T * I);
     const uint32_t ntiles = (uint32_t)((n_records + tile - 1) / tile);
     uint32_t *ticket = &h->d_ctrl->head.ticket;
     MGS_HIP(h, hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream));
-    const uint32_t grid = std::min<uint32_t>(ntiles, (uint32_t)(h->num_cus * V.blocks_per_cu));
+    const uint32_t grid = std::min<uint32_t>(ntiles, (uint32_t)(h->num_cus * 2));
     MGS_HIP(h, hipEventRecord(h->ev0, stream));
-    hipLaunchKernelGGL(V.copy, dim3(grid), dim3(V.threads), 0, stream,
+    hipLaunchKernelGGL((k_copy16<T, I, 0>), dim3(grid), dim3(T), 0, stream,
                        static_cast<const uint4 *>(d_in), static_cast<uint4 *>(d_out), n_records,
                        ntiles, ticket);
     MGS_HIP(h, hipEventRecord(h->ev1, stream));

@@ -98,6 +98,27 @@ __host__ __device__ __forceinline__ uint32_t hash_rec16(uint32_t w0, uint32_t w1
     return c;
 }
 
+// The same hash with the key's byte count turned into one mask per word on the
+// host (word w keeps its first clamp(klen - 4w, 0, 4) bytes): no per-record
+// selects.  km[3] is only used for keys longer than 12 bytes.
+__host__ __device__ __forceinline__ uint32_t hash_rec16m(uint32_t w0, uint32_t w1, uint32_t w2,
+                                                         uint32_t w3, uint32_t klen,
+                                                         const uint32_t (&km)[4])
+{
+    uint32_t a, b, c;
+    a = b = c = 0xdeadbeefu + klen;
+    if (klen > 12) {
+        a += w0; b += w1; c += w2;
+        MGS_MIX(a, b, c);
+        a += w3 & km[3];
+    }
+    else {
+        a += w0 & km[0]; b += w1 & km[1]; c += w2 & km[2];
+    }
+    MGS_FINAL(a, b, c);
+    return c;
+}
+
 // ---------------------------------------------------------------------------
 // dest = hash % (uint32_t) nranks (src/baseshuffler.h:277) without a divide:
 // round-up multiply-high division (exact for every 32-bit numerator), then
@@ -129,6 +150,24 @@ inline FastMod make_fastmod(uint32_t d)
         f.shift = L;
     }
     return f;
+}
+
+// The two cases of fastmod as separate functions, for callers that hoist the
+// (uniform) choice between them out of their inner loop.
+__host__ __device__ __forceinline__ uint32_t fastmod_pow2(uint32_t n, const FastMod &f)
+{
+    return n & (f.d - 1);
+}
+
+__host__ __device__ __forceinline__ uint32_t fastmod_magic(uint32_t n, const FastMod &f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t hi = __umulhi(f.magic, n);
+#else
+    const uint32_t hi = (uint32_t)(((uint64_t) f.magic * (uint64_t) n) >> 32);
+#endif
+    const uint32_t q = (((n - hi) >> 1) + hi) >> f.shift;
+    return n - q * f.d;
 }
 
 __host__ __device__ __forceinline__ uint32_t fastmod(uint32_t n, const FastMod &f)

@@ -51,6 +51,11 @@ constexpr int OSV_EARLY_AGG = 32;  // the last worker wave to finish hashing pub
 constexpr int OSV_LATE_TICKET = 64; // draw the next tile after barrier A instead of before it
 constexpr int OSV_WIDE_FIRST = 128; // every poll of the chained scan uses the full window
 constexpr int OSV_DELAY_SHIFT = 8;  // bits 8-9: pause before the chained scan's first poll (0 none, 1-3 longer)
+constexpr int OSV_SPEC8 = 1024;      // experiment: 8-byte keys, 8 destinations, no dest_out, as constants
+constexpr int OSV_KLEN8 = 2048;      // experiment: 8-byte keys as a constant
+constexpr int OSV_NB3 = 4096;        // experiment: 8 destinations as a constant
+constexpr int OSV_NODEST = 8192;     // experiment: no dest_out
+constexpr int OSV_WINDOW = 16384;     // windowed chained scan (16-bit counts + candidate bases)
 constexpr int OS_LOOK0 = 8;
 constexpr int OSV_STATS = 16;      // diagnostic: count polls / depth / cycles of the chained scan
 
@@ -61,12 +66,15 @@ struct OsParams {
     uint32_t P;
     int32_t self;
     uint32_t klen;  // key bytes (1..16)
+    uint32_t kmask[4]; // per key word: mask of the bytes that belong to the key
     uint32_t nbits; // ceil(log2(P)), >= 1
     uint32_t nbits_pad; // ceil(log2(P)), >= 0: lanes per predecessor in the chained scan = 1 << nbits_pad
     FastMod fm;
     uint32_t ntiles;
     uint32_t tile_records;
     unsigned long long *status; // [ntiles][P]
+    unsigned long long *agg16;  // [ntiles][1 << lpt_log]: 16-bit counts, four per word (windowed scan only)
+    uint32_t lpt_log;           // log2 of the words per tile in agg16
     uint8_t *dest_out;          // optional
     Ctrl *ctrl;
 };

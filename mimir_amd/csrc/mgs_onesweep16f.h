@@ -20,7 +20,7 @@
 #ifndef MGS_ONESWEEP16F_H
 #define MGS_ONESWEEP16F_H
 
-#include "mgs_onesweep16s.h"
+#include "mgs_onesweep16w.h"
 
 namespace mgs {
 
@@ -40,7 +40,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16f(OsParams p)
     __shared__ volatile uint32_t misc[8]; // [0] first tile, [2+j] next tile of trip parity j, [4+j] its trip tag
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t P = p.P;
+    constexpr bool S_NB = (VAR & OSV_NB3) != 0, S_KL = (VAR & OSV_KLEN8) != 0;
+    const uint32_t P = S_NB ? 8u : p.P;
+    const uint32_t nbits = S_NB ? 3u : p.nbits;
+    const uint32_t klen = S_KL ? 8u : p.klen;
 
     if (tid < OS_MAXP) {
         const bool live = (uint32_t) tid < P;
@@ -76,9 +79,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16f(OsParams p)
                     os_store_status(p.status + lane, OS_FLAG_INCL | (start + tot));
                 }
             }
-            else if (!(VAR & OSV_EARLY_AGG) && (uint32_t) lane < P) {
+            else if (!(VAR & (OSV_EARLY_AGG | OSV_WINDOW)) && (uint32_t) lane < P) {
                 os_store_status(p.status + (uint64_t) tile * P + lane, OS_FLAG_AGG | tot);
             }
+            if (VAR & OSV_WINDOW) os_publish_agg16(p, tile, lane, tot);
             // Draw the next tile at a fixed point of the workers' trip (right after barrier
             // A), so that every tile's counts are published about one trip after its
             // ticket: neighbouring tiles then publish close together and no walk waits long
@@ -103,7 +107,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16f(OsParams p)
                     if (DELAY == 1) __builtin_amdgcn_s_sleep(24);
                     if (DELAY == 2) __builtin_amdgcn_s_sleep(48);
                     if (DELAY == 3) __builtin_amdgcn_s_sleep(80);
-                    acc = os_chain_walk<VAR | OSV_WIDE_FIRST, LOOK>(p, tile, lane, &ws);
+                    if (VAR & OSV_WINDOW) acc = os_window_walk<VAR, LOOK>(p, tile, lane, &ws);
+                    else acc = os_chain_walk<VAR | OSV_WIDE_FIRST, LOOK>(p, tile, lane, &ws);
                 }
                 if ((uint32_t) lane < P) {
                     if (!(VAR & OSV_FAKE_CHAIN))
@@ -136,11 +141,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16f(OsParams p)
         for (int k = 0; k < ITEMS; k++) {
             const uint64_t i = idx0 + (uint32_t) k * 64;
             const bool valid = i < p.n;
-            const uint32_t h = hash_rec16(r[k].x, r[k].y, r[k].z, r[k].w, p.klen);
-            const uint32_t d = fastmod(h, p.fm);
+            const uint32_t h = hash_rec16(r[k].x, r[k].y, r[k].z, r[k].w, klen);
+            const uint32_t d = S_NB ? (h & 7u) : fastmod(h, p.fm);
             if (p.dest_out && valid) p.dest_out[i] = (uint8_t) d;
             uint64_t m = __ballot(valid);
-            for (uint32_t bit = 0; bit < p.nbits; bit++) {
+#pragma unroll
+            for (uint32_t bit = 0; bit < nbits; bit++) {
                 const bool one = (d >> bit) & 1u;
                 const uint64_t bk = __ballot(one);
                 m &= one ? bk : ~bk;

@@ -34,7 +34,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16p(OsParams p)
     volatile uint32_t *misc = reinterpret_cast<uint32_t *>(pcap + OS_MAXP);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t P = p.P;
+    constexpr bool SPEC = (VAR & OSV_SPEC8) != 0;
+    const uint32_t P = SPEC ? 8u : p.P;
+    const uint32_t nbits = SPEC ? 3u : p.nbits;
+    const uint32_t klen = SPEC ? 8u : p.klen;
 
     if (tid < OS_MAXP) {
         const bool live = (uint32_t) tid < P;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16p(OsParams p)
             const uint32_t s = (uint32_t) k * WTHREADS + tid;
             if (s < total) {
                 uint32_t b = 0;
-                for (uint32_t step = 1u << (p.nbits - 1); step > 0; step >>= 1) {
+                for (uint32_t step = 1u << (nbits - 1); step > 0; step >>= 1) {
                     const uint32_t nb = b + step;
                     if (nb < P && binstart[nb] <= s) b = nb;
                 }
@@ -139,11 +142,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16p(OsParams p)
         for (int k = 0; k < ITEMS; k++) {
             const uint64_t i = idx0 + (uint32_t) k * 64;
             const bool valid = i < p.n;
-            const uint32_t h = hash_rec16(r[k].x, r[k].y, r[k].z, r[k].w, p.klen);
-            const uint32_t d = fastmod(h, p.fm);
-            if (p.dest_out && valid) p.dest_out[i] = (uint8_t) d;
+            const uint32_t h = hash_rec16(r[k].x, r[k].y, r[k].z, r[k].w, klen);
+            const uint32_t d = SPEC ? (h & 7u) : fastmod(h, p.fm);
+            if (!SPEC && p.dest_out && valid) p.dest_out[i] = (uint8_t) d;
             uint64_t m = __ballot(valid);
-            for (uint32_t bit = 0; bit < p.nbits; bit++) {
+#pragma unroll
+            for (uint32_t bit = 0; bit < nbits; bit++) {
                 const bool one = (d >> bit) & 1u;
                 const uint64_t bk = __ballot(one);
                 m &= one ? bk : ~bk;

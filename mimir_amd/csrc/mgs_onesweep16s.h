@@ -54,8 +54,22 @@ struct OssGeom {
 struct OsWalkStats { // per scan wave, flushed to Ctrl::stats once at the end of the kernel
     unsigned long long tiles = 0, polls = 0, idle = 0, depth = 0, cycles = 0;
     unsigned long long max_depth = 0, max_cycles = 0, max_polls = 0;
+    // windowed scan only: first polls that did not finish, by cause
+    unsigned long long fail_near = 0, fail_far = 0, fail_base = 0;
+    bool windowed = false;
     __device__ void flush(Ctrl *ctrl) const
     {
+        if (windowed) {
+            atomicAdd(&ctrl->head.stats[0], tiles);
+            atomicAdd(&ctrl->head.stats[1], polls);
+            atomicAdd(&ctrl->head.stats[2], idle);
+            atomicAdd(&ctrl->head.stats[3], depth);
+            atomicAdd(&ctrl->head.stats[4], cycles);
+            atomicAdd(&ctrl->head.stats[5], fail_near);
+            atomicAdd(&ctrl->head.stats[6], fail_far);
+            atomicAdd(&ctrl->head.stats[7], fail_base);
+            return;
+        }
         atomicAdd(&ctrl->head.stats[0], tiles);
         atomicAdd(&ctrl->head.stats[1], polls);
         atomicAdd(&ctrl->head.stats[2], idle);

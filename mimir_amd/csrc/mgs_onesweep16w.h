@@ -1,0 +1,467 @@
+// k_onesweep16q: the split-loop LDS-image one-sweep kernel (see
+// mgs_onesweep16p.h) with a windowed chained scan.
+//
+// The chained scan of the other kernels walks back from tile i-1 until it
+// meets a tile that has published its inclusive prefix; one poll covers 128
+// predecessors.  When tiles are handed out faster than (window / poll round
+// trip) the nearest inclusive prefix lies outside the window, the walk needs a
+// second dependent round trip, finishes later, publishes later, and the walks
+// behind it get deeper still: the scan, not HBM, then sets the pace.
+//
+// Here a tile publishes two things in two arrays:
+//   agg16[tile]   its per-destination counts as 16-bit fields (count + 1,
+//                 0 = not published yet), four destinations per 8-byte word,
+//                 written once at barrier A and never changed;
+//   status[tile]  its inclusive prefix (64-bit per destination), written when
+//                 its own scan is done.
+// One poll of the scan loads the counts of the `window` nearest predecessors
+// (LOOK wave-wide loads; 384 tiles for 8 destinations, half the bytes of the
+// 64-bit entries) AND, in the same breath, the inclusive prefixes of several
+// candidate base tiles at distances step, 2*step, ... (one more load: lane =
+// (candidate, destination)).  The nearest candidate that is published, with
+// all counts nearer than it published, finishes the scan in this one round
+// trip: prefix(i) = inclusive(base) + sum of counts of base+1 .. i-1.  If no
+// candidate qualifies the published part of the window is accumulated and the
+// window moves back, so the scan stays correct at any depth.
+#ifndef MGS_ONESWEEP16W_H
+#define MGS_ONESWEEP16W_H
+
+#include "mgs_onesweep16s.h"
+
+namespace mgs {
+
+constexpr unsigned long long OS_AGG16_ONES = 0x0001000100010001ull;
+constexpr unsigned long long OS_AGG16_EVEN = 0x0000ffff0000ffffull;
+
+// Publish the counts of `tile` (lane = destination holds `tot`).
+__device__ __forceinline__ void os_publish_agg16(const OsParams &p, uint32_t tile, int lane, uint32_t tot)
+{
+    const uint32_t lpt = 1u << p.lpt_log;
+    unsigned long long word = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = (uint32_t) __shfl((int) tot, (lane * 4 + k) & 63);
+        word |= (unsigned long long) ((c + 1u) & 0xffffu) << (16 * k);
+    }
+    if ((uint32_t) lane < lpt) os_store_status(p.agg16 + (uint64_t) tile * lpt + lane, word);
+}
+
+// The windowed chained scan for `tile` (> 0), run by one whole wave.  Returns,
+// in lanes b < P, the number of records of destination b in all earlier tiles
+// plus the initial fill.
+template <int VAR, int LOOK>
+__device__ __forceinline__ unsigned long long os_window_walk(const OsParams &p, uint32_t tile, int lane,
+                                                             OsWalkStats *ws = nullptr)
+{
+    const uint32_t P = p.P;
+    // counts: lane = (j, g): predecessor slot j of a load, word g of its row
+    const uint32_t lptl = p.lpt_log, lpt = 1u << lptl, tpl = 64u >> lptl;
+    const uint32_t j = (uint32_t) lane >> lptl, g = (uint32_t) lane & (lpt - 1);
+    const uint32_t window = (uint32_t) LOOK * tpl;
+    // candidates: lane = (c, b): candidate c, destination b
+    const uint32_t Pp = 1u << p.nbits_pad;
+    const uint32_t c = (uint32_t) lane >> p.nbits_pad, b = (uint32_t) lane & (Pp - 1);
+    const uint32_t ncand = 64u >> p.nbits_pad;
+    const uint32_t step = window / ncand;
+    const uint32_t dist = (c + 1) * step; // candidate base = look - dist, counts 0..dist-1 are needed
+    const bool bin_ok = b < P;
+    const uint64_t gmask = (Pp == 64) ? ~0ull : ((1ull << Pp) - 1ull);
+    const uint32_t gshift = c << p.nbits_pad;
+
+    unsigned long long acc_lo = 0, acc_hi = 0; // 32-bit fields: dests 4g+0 | 4g+2, 4g+1 | 4g+3
+    unsigned long long base = 0;
+    int64_t look = (int64_t) tile - 1; // nearest predecessor not yet accounted for
+    uint32_t cstar = 0;
+    bool done = false;
+    uint32_t idle = 0, st_polls = 0, st_idle = 0;
+    unsigned long long st_t0 = 0;
+    if (VAR & OSV_STATS) st_t0 = __builtin_readcyclecounter();
+
+    auto entry_ok = [](unsigned long long x) {
+        return (x & 0xffffull) && (x & 0xffff0000ull) && (x & 0xffff00000000ull)
+               && (x & 0xffff000000000000ull);
+    };
+    constexpr int DELAY = (VAR >> OSV_DELAY_SHIFT) & 3;
+    if (DELAY == 1) __builtin_amdgcn_s_sleep(16);
+    if (DELAY == 2) __builtin_amdgcn_s_sleep(32);
+    if (DELAY == 3) __builtin_amdgcn_s_sleep(64);
+    while (!done) {
+        unsigned long long v[LOOK];
+        // the far part of the window and the candidate bases first ...
+#pragma unroll
+        for (int q = 1; q < LOOK; q++) {
+            const int64_t t = look - (int64_t)((uint32_t) q * tpl + j);
+            v[q] = (t >= 0) ? os_load_status(p.agg16 + (uint64_t) t * lpt + g) : OS_AGG16_ONES;
+        }
+        const int64_t tb = look - (int64_t) dist;
+        unsigned long long cv;
+        if (!bin_ok) cv = OS_FLAG_INCL;
+        else if (tb >= 0) cv = os_load_status(p.status + (uint64_t) tb * P + b);
+        else cv = OS_FLAG_INCL | (unsigned long long) (p.ctrl->head.part_init[b] >> 4);
+        // ... the nearest predecessors last: they published their counts only moments
+        // ago, and every bit of time makes it likelier that this load sees them
+        const int64_t t0 = look - (int64_t) j;
+        v[0] = (t0 >= 0) ? os_load_status(p.agg16 + (uint64_t) t0 * lpt + g) : OS_AGG16_ONES;
+
+        // first predecessor beyond the nearest load whose counts are not published yet
+        uint32_t far_invalid = window;
+#pragma unroll
+        for (int q = LOOK - 1; q >= 1; q--) {
+            const uint64_t inv = ~__ballot(entry_ok(v[q]));
+            if (inv) far_invalid = (uint32_t) q * tpl + ((uint32_t)(__ffsll((unsigned long long) inv) - 1) >> lptl);
+        }
+        const uint64_t m_inc = __ballot((cv >> 62) == 2);
+        const bool g_ok = ((m_inc >> gshift) & gmask) == gmask;
+        uint32_t take; // predecessors accounted for by this poll
+        for (;;) {
+            const uint64_t inv0 = ~__ballot(entry_ok(v[0]));
+            const uint32_t near_invalid =
+                inv0 ? ((uint32_t)(__ffsll((unsigned long long) inv0) - 1) >> lptl) : tpl;
+            const uint32_t first_invalid = near_invalid < tpl ? near_invalid : far_invalid;
+            // nearest candidate that is published and has all nearer counts
+            const uint64_t usable = __ballot(g_ok && dist <= first_invalid);
+            if (usable) {
+                cstar = (uint32_t)(__ffsll((unsigned long long) usable) - 1) >> p.nbits_pad;
+                take = (cstar + 1) * step;
+                done = true;
+                break;
+            }
+            take = first_invalid;
+            if ((VAR & OSV_STATS) && ws && st_polls == 0) {
+                ws->windowed = true;
+                if (near_invalid < tpl) ws->fail_near++;
+                else if (far_invalid < window) ws->fail_far++;
+                else ws->fail_base++;
+            }
+            // Only some of the nearest predecessors are missing and a candidate is ready
+            // behind them: poll just that one load again, everything else stays valid.
+            const bool near_only = near_invalid < tpl && __ballot(g_ok && dist <= far_invalid) != 0;
+            if (!near_only) break;
+            if (VAR & OSV_STATS) {
+                st_polls++;
+                st_idle++;
+            }
+            if (++idle > OS_SPIN_LIMIT
+                || ((idle & 255u) == 0
+                    && __hip_atomic_load(&p.ctrl->head.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                break; // the outer loop's bounded wait deals with it
+            __builtin_amdgcn_s_sleep(1);
+            v[0] = (t0 >= 0) ? os_load_status(p.agg16 + (uint64_t) t0 * lpt + g) : OS_AGG16_ONES;
+        }
+#pragma unroll
+        for (int q = 0; q < LOOK; q++) {
+            if ((uint32_t) q * tpl + j < take) {
+                const unsigned long long u = v[q] - OS_AGG16_ONES;
+                acc_lo += u & OS_AGG16_EVEN;
+                acc_hi += (u >> 16) & OS_AGG16_EVEN;
+            }
+        }
+        look -= take;
+        if (done) base = cv & OS_VALUE_MASK;
+        if (VAR & OSV_STATS) {
+            st_polls++;
+            if (take == 0) st_idle++;
+        }
+        if (!done) {
+            if (take == 0) {
+                // Bounded wait: give up after OS_SPIN_LIMIT empty polls, and leave at
+                // once when any other tile has already given up.
+                ++idle;
+                if (idle > OS_SPIN_LIMIT) {
+                    raise_error(p.ctrl, MGS_ERR_TIMEOUT);
+                    done = true;
+                }
+                else if ((idle & 255u) == 0
+                         && __hip_atomic_load(&p.ctrl->head.error, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    done = true;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            else {
+                idle = 0;
+            }
+        }
+    }
+    // add up the lanes that hold the same word of different predecessors
+    for (uint32_t s = lpt; s < 64u; s <<= 1) {
+        acc_lo += (unsigned long long) __shfl_xor((long long) acc_lo, (int) s);
+        acc_hi += (unsigned long long) __shfl_xor((long long) acc_hi, (int) s);
+    }
+    // lane b: its field of word b/4, and the base prefix of candidate cstar
+    const int src = (int) ((uint32_t) lane >> 2) & (int) (lpt - 1);
+    const unsigned long long lo = (unsigned long long) __shfl((long long) acc_lo, src);
+    const unsigned long long hi = (unsigned long long) __shfl((long long) acc_hi, src);
+    const unsigned long long pick = (lane & 1) ? hi : lo;
+    const unsigned long long sum = (lane & 2) ? (pick >> 32) : (pick & 0xffffffffull);
+    const unsigned long long bv =
+        (unsigned long long) __shfl((long long) base, (int) ((cstar << p.nbits_pad) | b));
+    if ((VAR & OSV_STATS) && ws) {
+        const unsigned long long dt = __builtin_readcyclecounter() - st_t0;
+        const unsigned long long depth = (unsigned long long) ((int64_t) tile - 1 - look);
+        ws->tiles += 1;
+        ws->polls += st_polls;
+        ws->idle += st_idle;
+        ws->depth += depth;
+        ws->cycles += dt;
+        ws->max_depth = depth > ws->max_depth ? depth : ws->max_depth;
+        ws->max_cycles = dt > ws->max_cycles ? dt : ws->max_cycles;
+        ws->max_polls = st_polls > ws->max_polls ? st_polls : ws->max_polls;
+    }
+    return bv + sum;
+}
+
+// Hash the ITEMS rows a wave holds of a tile, find every record's destination,
+// its rank among the records of the same destination in its row and that
+// group's size (a match-any over the destination bits: NB wave ballots), and
+// add the group sizes to the wave's per-destination counts in LDS.  The two
+// wave-uniform choices (power-of-two modulus, key longer than 12 bytes) are
+// template parameters so that the loop body is one straight run of code.
+template <int ITEMS, int NB, bool POW2, bool LONGKEY>
+__device__ __forceinline__ void os_hash_rows(const OsParams &p, const uint4 (&r)[ITEMS], uint64_t idx0,
+                                             uint32_t *wave_counts, uint32_t (&meta)[ITEMS])
+{
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const bool valid = idx0 + (uint32_t) k * 64 < p.n;
+        uint32_t a, b, c;
+        a = b = c = 0xdeadbeefu + p.klen;
+        if (LONGKEY) {
+            a += r[k].x; b += r[k].y; c += r[k].z;
+            MGS_MIX(a, b, c);
+            a += r[k].w & p.kmask[3];
+        }
+        else {
+            a += r[k].x & p.kmask[0]; b += r[k].y & p.kmask[1]; c += r[k].z & p.kmask[2];
+        }
+        MGS_FINAL(a, b, c);
+        const uint32_t d = POW2 ? fastmod_pow2(c, p.fm) : fastmod_magic(c, p.fm);
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (uint32_t bit = 0; bit < (uint32_t) NB; bit++) {
+            const bool one = (d >> bit) & 1u;
+            const uint64_t bk = __ballot(one);
+            m &= one ? bk : ~bk;
+        }
+        const uint32_t rank = lanes_below(m);
+        const uint32_t cnt = (uint32_t) __popcll(m);
+        if (valid && rank == 0) atomicAdd(&wave_counts[d], cnt);
+        meta[k] = d | (rank << 8) | (cnt << 16) | (valid ? 0x80000000u : 0u);
+    }
+}
+
+// NB: number of destination bits (ceil(log2(P)), at least 1) as a constant, so
+// that the match-any loop and the search for a slot's destination unroll.
+//
+// Per tile the scan wave leaves in LDS, for the workers' deferred store:
+//   addr[b]  = address of partition b's byte 0 + 16 * (position of the tile's
+//              first record of b in the partition - first slot of b in the
+//              image), so that slot s of the image goes to addr[dest(s)] + 16*s;
+//   fits     = every record of the tile lies below its partition's capacity.
+// A tile that fits is stored with one table read per record; any other tile
+// takes the checked path (capacity test per record, round cut, local overflow).
+template <int THREADS, int ITEMS, int VAR, int MINW, int LOOK, int NB>
+__global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
+{
+    constexpr int WORKERS = THREADS / 64 - 1, TILE = WORKERS * 64 * ITEMS;
+    constexpr int WTHREADS = WORKERS * 64;
+    constexpr int CNT = WORKERS * OS_MAXP;
+    static_assert(TILE < 65535, "a tile's count must fit a 16-bit field");
+    __shared__ __attribute__((aligned(16))) uint4 srec[TILE];   // tile image, grouped by destination
+    __shared__ uint8_t sdest[TILE];                             // destination of every image slot
+    __shared__ uint32_t wcnt[2 * CNT];                          // per (wave, dest) counts, two tiles
+    __shared__ volatile uint32_t wslot[CNT];                    // running slot per (wave, dest)
+    __shared__ uint32_t binstart2[2 * (OS_MAXP + 4)];           // dest -> first slot (+ total), two tiles
+    __shared__ unsigned long long gpos2[2 * OS_MAXP];           // dest -> position of the tile, two tiles
+    __shared__ unsigned long long addr2[2 * OS_MAXP];           // see above, two tiles
+    __shared__ unsigned long long pbase[OS_MAXP];
+    __shared__ unsigned long long pcap[OS_MAXP];
+    __shared__ volatile uint32_t misc[4]; // [0] first tile, [1] next tile, [2+par] fits
+    __shared__ uint32_t arrive[2];        // worker waves done hashing, per tile parity
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr bool S_ND = (VAR & OSV_NODEST) != 0;
+    const uint32_t P = p.P;
+    constexpr uint32_t nbits = NB;
+
+    if (tid < OS_MAXP) {
+        const bool live = (uint32_t) tid < P;
+        pbase[tid] = live ? p.ctrl->head.part_base[tid] : 0ull;
+        pcap[tid] = live ? (unsigned long long) (p.ctrl->head.part_cap[tid] >> 4) : 0ull;
+    }
+    for (int j = tid; j < 2 * CNT; j += THREADS) wcnt[j] = 0;
+    if (tid == 0) {
+        arrive[0] = 0;
+        arrive[1] = 0;
+        misc[0] = atomicAdd(&p.ctrl->head.ticket, 1u);
+    }
+    __syncthreads();
+    uint32_t tile = misc[0];
+    int par = 0;
+
+    // ------------------------------------------------------------------ scan wave
+    if (w == WORKERS) {
+        OsWalkStats ws;
+        const unsigned long long my_base = pbase[lane], my_cap = pcap[lane];
+        while (tile < p.ntiles) {
+            const uint32_t *wc = wcnt + par * CNT;
+            __syncthreads(); // A: counts(tile) complete
+            uint32_t tot = 0; // lane = destination
+#pragma unroll
+            for (int ww = 0; ww < WORKERS; ww++) tot += wc[ww * OS_MAXP + lane];
+            if (!(VAR & OSV_EARLY_AGG)) os_publish_agg16(p, tile, lane, tot); // before anything else
+            unsigned long long acc = 0;
+            if (tile == 0) {
+                acc = ((uint32_t) lane < P) ? (unsigned long long) (p.ctrl->head.part_init[lane] >> 4) : 0ull;
+                if ((uint32_t) lane < P) os_store_status(p.status + lane, OS_FLAG_INCL | (acc + tot));
+            }
+            // draw the next tile now: a short time between a tile's ticket and the
+            // publication of its counts keeps neighbouring tiles close in time
+            if (lane == 0) misc[1] = atomicAdd(&p.ctrl->head.ticket, 1u);
+            // the other copy of the counts was last read before the previous barrier B
+            for (int j = lane; j < CNT; j += 64) wcnt[(par ^ 1) * CNT + j] = 0;
+            if (lane == 0) arrive[par ^ 1] = 0;
+            const uint32_t first_slot = wave_incl_scan_u32(tot, lane) - tot;
+            __syncthreads(); // B
+            const uint32_t next = misc[1];
+            if (tile != 0) {
+                if (VAR & OSV_FAKE_CHAIN) acc = (unsigned long long) tile * (TILE / P);
+                else acc = os_window_walk<VAR, LOOK>(p, tile, lane, &ws);
+                if (!(VAR & OSV_FAKE_CHAIN) && (uint32_t) lane < P)
+                    os_store_status(p.status + (uint64_t) tile * P + lane,
+                                    OS_FLAG_INCL | ((acc + tot) & OS_VALUE_MASK));
+            }
+            const bool over = (uint32_t) lane < P && acc + tot > my_cap;
+            const bool fits = __ballot(over) == 0;
+            gpos2[par * OS_MAXP + lane] = acc;
+            addr2[par * OS_MAXP + lane] = my_base + ((acc - first_slot) << 4);
+            if (lane == 0) misc[2 + par] = fits ? 1u : 0u;
+            tile = next;
+            par ^= 1;
+        }
+        __syncthreads(); // matches the workers' last barrier
+        if ((VAR & OSV_STATS) && lane == 0) ws.flush(p.ctrl);
+        return;
+    }
+
+    // ------------------------------------------------------------------- workers
+    uint32_t prev = 0xFFFFFFFFu; // tile whose image waits in LDS to be stored
+    uint4 r[ITEMS];
+    if (tile < p.ntiles) os_load_tile<ITEMS, VAR>(p, tile, TILE, w, lane, r);
+
+    // Store the LDS image of a tile: consecutive lanes write consecutive
+    // 16-byte slots of one partition run.
+    auto store_image = [&](uint32_t t, int pr) {
+        const uint32_t total = binstart2[pr * (OS_MAXP + 4) + 64];
+        if (misc[2 + pr] != 0) {
+            const unsigned long long *addr = addr2 + pr * OS_MAXP;
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const uint32_t s = (uint32_t) k * WTHREADS + tid;
+                if (s < total)
+                    *reinterpret_cast<uint4 *>(addr[sdest[s]] + ((unsigned long long) s << 4)) = srec[s];
+            }
+            return;
+        }
+        const uint32_t *binstart = binstart2 + pr * (OS_MAXP + 4);
+        const unsigned long long *gpos = gpos2 + pr * OS_MAXP;
+        bool overflow = false;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t s = (uint32_t) k * WTHREADS + tid;
+            if (s < total) {
+                const uint32_t b = sdest[s];
+                const unsigned long long pos = gpos[b] + (s - binstart[b]);
+                if (pos < pcap[b]) {
+                    reinterpret_cast<uint4 *>(pbase[b])[pos] = srec[s];
+                }
+                else if ((int32_t) b == p.self) {
+                    raise_error(p.ctrl, MGS_ERR_LOCAL_OVERFLOW);
+                }
+                else {
+                    overflow = true;
+                }
+            }
+        }
+        if (overflow) atomicMin(&p.ctrl->head.cut_tile, t);
+    };
+
+    while (tile < p.ntiles) {
+        uint32_t *wc = wcnt + par * CNT;
+        uint32_t meta[ITEMS]; // dest | rank<<8 | count<<16 | valid<<31
+        const uint64_t idx0 = (uint64_t) tile * TILE + (uint32_t) w * (ITEMS * 64) + lane;
+        if (p.fm.pow2) {
+            if (p.klen > 12) os_hash_rows<ITEMS, NB, true, true>(p, r, idx0, wc + w * OS_MAXP, meta);
+            else os_hash_rows<ITEMS, NB, true, false>(p, r, idx0, wc + w * OS_MAXP, meta);
+        }
+        else {
+            if (p.klen > 12) os_hash_rows<ITEMS, NB, false, true>(p, r, idx0, wc + w * OS_MAXP, meta);
+            else os_hash_rows<ITEMS, NB, false, false>(p, r, idx0, wc + w * OS_MAXP, meta);
+        }
+        if (!S_ND && p.dest_out) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++)
+                if ((meta[k] >> 31) != 0) p.dest_out[idx0 + (uint32_t) k * 64] = (uint8_t) (meta[k] & 0xffu);
+        }
+        if (VAR & OSV_EARLY_AGG) {
+            // The last worker wave to finish hashing publishes the tile's counts, before
+            // barrier A: a scan wave that arrives late at the barrier (a long scan for the
+            // previous tile) then holds back only its own workgroup, not every later tile
+            // whose scan needs these counts.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            uint32_t arrived = 0;
+            if (lane == 0) arrived = atomicAdd(&arrive[par], 1u);
+            arrived = __builtin_amdgcn_readfirstlane(arrived);
+            if (arrived == (uint32_t) WORKERS - 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                uint32_t tot_all = 0;
+#pragma unroll
+                for (int ww = 0; ww < WORKERS; ww++)
+                    tot_all += ((volatile uint32_t *) wc)[ww * OS_MAXP + lane];
+                os_publish_agg16(p, tile, lane, tot_all);
+            }
+        }
+        __syncthreads(); // A: counts(tile) complete; image(prev) and position(prev) ready
+
+        uint32_t tot = 0, below = 0; // lane = destination
+#pragma unroll
+        for (int ww = 0; ww < WORKERS; ww++) {
+            const uint32_t v = wc[ww * OS_MAXP + lane];
+            tot += v;
+            if (ww < w) below += v;
+        }
+        const uint32_t incl = wave_incl_scan_u32(tot, lane);
+        wslot[w * OS_MAXP + lane] = incl - tot + below;
+        if (w == 0) {
+            uint32_t *binstart = binstart2 + par * (OS_MAXP + 4);
+            binstart[lane] = incl - tot;
+            if (lane == 63) binstart[64] = incl;
+        }
+        if (prev != 0xFFFFFFFFu) store_image(prev, par ^ 1);
+        __syncthreads(); // B: every slot of image(prev) has been read, the image is free
+        const uint32_t next = misc[1];
+
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t d = meta[k] & 0xffu, rank = (meta[k] >> 8) & 0xffu;
+            const uint32_t cnt = (meta[k] >> 16) & 0xffu;
+            if ((meta[k] >> 31) != 0) {
+                const uint32_t base = wslot[w * OS_MAXP + d];
+                if (rank == 0) wslot[w * OS_MAXP + d] = base + cnt;
+                srec[base + rank] = r[k];
+                sdest[base + rank] = (uint8_t) d;
+            }
+        }
+        // the registers are free again: fetch the next tile
+        if (next < p.ntiles) os_load_tile<ITEMS, VAR>(p, next, TILE, w, lane, r);
+        prev = tile;
+        tile = next;
+        par ^= 1;
+    }
+    __syncthreads(); // image(prev) and position(prev) ready
+    if (prev != 0xFFFFFFFFu) store_image(prev, par ^ 1);
+    (void) nbits;
+}
+
+} // namespace mgs
+#endif

@@ -43,9 +43,11 @@ def main():
             if names[v].endswith("-stats") and rnd == rounds:
                 st = pk.debug_stats()
                 t = max(st[0], 1)
+                tail = (f"first poll unfinished: near counts {st[5]/t:.3f} far counts {st[6]/t:.3f} "
+                        f"no base {st[7]/t:.3f} per tile" if names[v][0] in "qg" else
+                        f"max_depth={st[5]} max_cycles={st[6]} max_polls={st[7]}")
                 print(f"[{names[v]}] tiles={st[0]} polls/tile={st[1]/t:.2f} idle/tile={st[2]/t:.2f} "
-                      f"depth/tile={st[3]/t:.1f} cycles/tile={st[4]/t:.0f} max_depth={st[5]} "
-                      f"max_cycles={st[6]} max_polls={st[7]}")
+                      f"depth/tile={st[3]/t:.1f} cycles/tile={st[4]/t:.0f} {tail}")
             if "fake" not in names[v]:
                 if ref is None:
                     ref = r.send_offset.copy()
