@@ -69,8 +69,14 @@ enum {
     MGS_ALGO_AUTO = 0,     /* fastest kernel that supports the layout        */
     MGS_ALGO_GENERIC = 1,  /* three-pass histogram / scan / scatter, any
                               layout, any nranks <= MGS_MAX_RANKS             */
-    MGS_ALGO_ONESWEEP16 = 2 /* single-pass chained-scan kernel for 16-byte
+    MGS_ALGO_ONESWEEP16 = 2, /* single-pass chained-scan kernel for 16-byte
                               fixed-width records, nranks <= 64               */
+    MGS_ALGO_ONESWEEPV = 3  /* single-pass chained-scan kernel for
+                              byte-granular records: variable width, or fixed
+                              widths up to 19 bytes; nranks <= 64 (63 with a
+                              local rank).  Variable-width batches whose
+                              records are too long for its LDS staging fall
+                              back to GENERIC inside the call                 */
 };
 
 typedef struct mgs_desc {

@@ -13,7 +13,7 @@ MGS_MAX_RANKS = 256
 
 KEY_FIXED, KEY_CSTR = 0, 1
 VAL_VOID, VAL_FIXED, VAL_CSTR = 0, 1, 2
-ALGO_AUTO, ALGO_GENERIC, ALGO_ONESWEEP16 = 0, 1, 2
+ALGO_AUTO, ALGO_GENERIC, ALGO_ONESWEEP16, ALGO_ONESWEEPV = 0, 1, 2, 3
 
 OK = 0
 ERR_ARG, ERR_HIP, ERR_RECORD_SIZE, ERR_LOCAL_OVERFLOW = -1, -2, -3, -4

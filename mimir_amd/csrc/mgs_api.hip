@@ -18,6 +18,7 @@
 #include "mgs_onesweep16p.h"
 #include "mgs_onesweep16f.h"
 #include "mgs_onesweep16w.h"
+#include "mgs_onesweepv.h"
 
 using namespace mgs;
 
@@ -134,6 +135,8 @@ struct mgs_handle {
     // one-sweep path scratch
     unsigned long long *d_status = nullptr;
     unsigned long long *d_agg16 = nullptr;
+    size_t status_bytes = 0, agg16_bytes = 0;
+    bool pending_osv = false; // the byte-granular one-sweep path was enqueued (may have fallen back)
     // call in flight
     bool pending = false;
     hipStream_t pending_stream = nullptr;
@@ -316,18 +319,40 @@ static int ensure_generic_scratch(mgs_handle *h, bool need_dest)
     return MGS_OK;
 }
 
-static int ensure_onesweep_scratch(mgs_handle *h)
+// One-sweep scratch: status u64[tiles][columns] and the 16-bit count words
+// ((1 << lpt_log) <= 2 * ceil(columns / 4) words per tile), sized for the
+// smallest tile any instantiation uses.
+static int ensure_onesweep_scratch(mgs_handle *h, int min_tile, int columns)
 {
-    int min_tile = kOsVariants[0].tile; // sized for any variant mgs_set_tuning may select
-    for (int v = 0; v < kNumOsVariants; v++) min_tile = std::min(min_tile, kOsVariants[v].tile);
     const uint64_t tiles = (h->desc.max_records + min_tile - 1) / min_tile;
-    if (!h->d_status)
-        MGS_HIP(h, hipMalloc(&h->d_status, tiles * (uint64_t) h->desc.nranks * sizeof(unsigned long long)));
-    if (!h->d_agg16) // (1 << lpt_log) <= 2 * ceil(nranks / 4) words per tile
-        MGS_HIP(h, hipMalloc(&h->d_agg16,
-                             tiles * (uint64_t) ((h->desc.nranks + 3) / 4 * 2) * sizeof(unsigned long long)));
+    const size_t sb = tiles * (uint64_t) columns * sizeof(unsigned long long);
+    const size_t ab = tiles * (uint64_t) ((columns + 3) / 4 * 2) * sizeof(unsigned long long);
+    if (h->status_bytes < sb) {
+        if (h->d_status) MGS_HIP(h, hipFree(h->d_status));
+        h->d_status = nullptr;
+        h->status_bytes = 0;
+        MGS_HIP(h, hipMalloc(&h->d_status, sb));
+        h->status_bytes = sb;
+    }
+    if (h->agg16_bytes < ab) {
+        if (h->d_agg16) MGS_HIP(h, hipFree(h->d_agg16));
+        h->d_agg16 = nullptr;
+        h->agg16_bytes = 0;
+        MGS_HIP(h, hipMalloc(&h->d_agg16, ab));
+        h->agg16_bytes = ab;
+    }
     return MGS_OK;
 }
+
+static int os16_min_tile()
+{
+    int min_tile = kOsVariants[0].tile; // any variant mgs_set_tuning may select
+    for (int v = 0; v < kNumOsVariants; v++) min_tile = std::min(min_tile, kOsVariants[v].tile);
+    return min_tile;
+}
+
+// The byte-granular one-sweep kernel: 512 threads, 4 records per worker lane.
+constexpr int kOvThreads = 512, kOvK = 4, kOvTile = (kOvThreads / 64 - 1) * 64 * kOvK;
 
 int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
                           uint64_t n_end, uint64_t start, const int64_t *init_offset,
@@ -390,13 +415,24 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
                  && ((uintptr_t) rec0 % 16) == 0 && ((uintptr_t) d_send_image % 16) == 0
                  && (D.rank < 0 || ((uintptr_t) d_local_out % 16) == 0);
     for (int b = 0; b < P && os_ok; b++) os_ok = (h->pending_init[b] % 16) == 0;
-    if (algo == MGS_ALGO_AUTO) algo = os_ok ? MGS_ALGO_ONESWEEP16 : MGS_ALGO_GENERIC;
+    // byte-granular one-sweep: chain columns = P (+1 for the local record count) <= 64, and for
+    // fixed widths a tile that fits the LDS staging buffer (variable widths are checked on the device)
+    const bool ov_ok = P + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
+                       && (h->fixed_len == 0
+                           || (uint64_t) kOvTile * h->fixed_len + 15 <= (uint64_t) OV_IN_BYTES);
+    if (algo == MGS_ALGO_AUTO)
+        algo = os_ok ? MGS_ALGO_ONESWEEP16 : (ov_ok ? MGS_ALGO_ONESWEEPV : MGS_ALGO_GENERIC);
+    if (algo == MGS_ALGO_ONESWEEPV && !ov_ok) {
+        h->err = "mgs_pack_device: ONESWEEPV needs nranks (+1 with a local rank) <= 64 and, for fixed "
+                 "widths, records of at most 19 bytes";
+        return MGS_ERR_ARG;
+    }
     if (algo == MGS_ALGO_ONESWEEP16 && !os_ok) {
         h->err = "mgs_pack_device: ONESWEEP16 needs 16-byte fixed records, nranks <= 64 and "
                  "16-byte aligned buffers/offsets";
         return MGS_ERR_ARG;
     }
-    if (algo != MGS_ALGO_ONESWEEP16 && algo != MGS_ALGO_GENERIC) {
+    if (algo != MGS_ALGO_ONESWEEP16 && algo != MGS_ALGO_GENERIC && algo != MGS_ALGO_ONESWEEPV) {
         h->err = "mgs_pack_device: unknown algo";
         return MGS_ERR_ARG;
     }
@@ -426,7 +462,7 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
     MGS_HIP(h, hipMemcpyAsync(h->d_ctrl, H, sizeof(CtrlHead), hipMemcpyHostToDevice, stream));
 
     if (algo == MGS_ALGO_ONESWEEP16) {
-        int rc = ensure_onesweep_scratch(h);
+        int rc = ensure_onesweep_scratch(h, os16_min_tile(), P);
         if (rc) return rc;
         OsParams p;
         p.rec = reinterpret_cast<const uint4 *>(rec0) + start;
@@ -449,6 +485,7 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         p.status = h->d_status;
         p.agg16 = h->d_agg16;
         p.lpt_log = p.nbits_pad > 2 ? p.nbits_pad - 2 : 0;
+        p.unit_shift = 4;
         p.dest_out = d_dest_out;
         p.ctrl = h->d_ctrl;
         MGS_HIP(h, hipMemsetAsync(h->d_status, 0, (size_t) p.ntiles * P * sizeof(unsigned long long), stream));
@@ -460,11 +497,58 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         MGS_HIP(h, hipEventRecord(h->ev1, stream));
         hipLaunchKernelGGL(k_os_finalize, dim3(1), dim3(64), 0, stream, p);
         h->last_algo = "onesweep16";
+        h->pending_osv = false;
     }
     else {
+        const bool osv = algo == MGS_ALGO_ONESWEEPV;
+        const bool may_fall_back = osv && h->fixed_len == 0;
+        h->pending_osv = osv;
+        if (osv) {
+            const int columns = P + (D.rank >= 0 ? 1 : 0);
+            int rc = ensure_onesweep_scratch(h, kOvTile, columns);
+            if (rc) return rc;
+            OvParams q;
+            memset(&q, 0, sizeof(q));
+            q.blob = rec0;
+            q.rec_off = h->fixed_len ? nullptr : d_rec_off;
+            q.fixed_len = h->fixed_len;
+            q.first = start;
+            q.n = n;
+            q.lay = D.layout;
+            q.P = (uint32_t) P;
+            OsParams &c = q.os;
+            c.n = n;
+            c.first = start;
+            c.P = (uint32_t) columns;
+            c.self = D.rank;
+            c.nbits = 1;
+            while ((1u << c.nbits) < (uint32_t) columns) c.nbits++;
+            c.nbits_pad = (columns == 1) ? 0 : c.nbits;
+            c.lpt_log = c.nbits_pad > 2 ? c.nbits_pad - 2 : 0;
+            c.unit_shift = 0;
+            c.fm = h->fm;
+            c.tile_records = (uint32_t) kOvTile;
+            c.ntiles = (uint32_t) ((n + kOvTile - 1) / kOvTile);
+            c.status = h->d_status;
+            c.agg16 = h->d_agg16;
+            c.dest_out = d_dest_out;
+            c.ctrl = h->d_ctrl;
+            MGS_HIP(h, hipMemsetAsync(h->d_status, 0, (size_t) c.ntiles * columns * sizeof(unsigned long long), stream));
+            MGS_HIP(h, hipMemsetAsync(h->d_agg16, 0, ((size_t) c.ntiles << c.lpt_log) * sizeof(unsigned long long), stream));
+            if (may_fall_back)
+                hipLaunchKernelGGL(k_osv_check, dim3((c.ntiles + 255) / 256), dim3(256), 0, stream, q);
+            const uint32_t grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2));
+            MGS_HIP(h, hipEventRecord(h->ev0, stream));
+            hipLaunchKernelGGL((k_onesweepv<kOvThreads, kOvK, 0, 4, 8>), dim3(grid), dim3(kOvThreads), 0, stream, q);
+            if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
+            hipLaunchKernelGGL(k_osv_finalize, dim3(1), dim3(64), 0, stream, q);
+            h->last_algo = "onesweepv";
+        }
+        if (!osv || may_fall_back) {
         int rc = ensure_generic_scratch(h, d_dest_out == nullptr);
         if (rc) return rc;
         GenParams p;
+        p.gate = may_fall_back ? 1u : 0u;
         p.blob = rec0;
         p.rec_off = h->fixed_len ? nullptr : d_rec_off;
         p.fixed_len = h->fixed_len;
@@ -481,11 +565,12 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         p.ctrl = h->d_ctrl;
         hipLaunchKernelGGL(k_gen_hist, dim3(p.ntiles), dim3(GEN_THREADS), 0, stream, p);
         hipLaunchKernelGGL(k_gen_scan, dim3(1), dim3(1024), 0, stream, p);
-        MGS_HIP(h, hipEventRecord(h->ev0, stream));
+        if (!osv) MGS_HIP(h, hipEventRecord(h->ev0, stream));
         hipLaunchKernelGGL(k_gen_scatter, dim3(p.ntiles), dim3(GEN_THREADS), 0, stream, p);
         MGS_HIP(h, hipEventRecord(h->ev1, stream));
         hipLaunchKernelGGL(k_gen_finalize, dim3(1), dim3(GEN_THREADS), 0, stream, p);
-        h->last_algo = "generic";
+        if (!osv) h->last_algo = "generic";
+        }
     }
     MGS_HIP(h, hipGetLastError());
     MGS_HIP(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
@@ -511,6 +596,7 @@ int mgs_pack_result(mgs_handle *h, mgs_round *out)
     DeviceGuard g(h->desc.device);
     MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
     h->ev_valid = true;
+    if (h->pending_osv && h->h_ctrl->head.fallback != 0) h->last_algo = "generic"; // fell back on the device
     const int derr = h->h_ctrl->head.error;
     if (derr != 0) {
         switch (derr) {

@@ -39,6 +39,7 @@ struct GenParams {
     uint32_t *tile_hist; // [ntiles][P+1]
     uint64_t *tile_base; // [ntiles+1][P+1]
     uint8_t *dest;       // [n] scratch (or the caller's d_dest_out)
+    uint32_t gate;       // 1: run only when Ctrl::head.fallback is raised (enqueued behind the one-sweep path)
     Ctrl *ctrl;
 };
 
@@ -89,6 +90,7 @@ __device__ inline bool gen_key_len(const mgs_layout &lay, const uint8_t *r,
 
 __global__ __launch_bounds__(GEN_THREADS) void k_gen_hist(GenParams p)
 {
+    if (p.gate && p.ctrl->head.fallback == 0) return;
     __shared__ uint32_t hist[MGS_MAX_RANKS + 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t tile = blockIdx.x;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_gen_hist(GenParams p)
 // (local-bypass record count) starts at 0.  Row ntiles receives the totals.
 __global__ __launch_bounds__(1024) void k_gen_scan(GenParams p)
 {
+    if (p.gate && p.ctrl->head.fallback == 0) return;
     __shared__ unsigned long long csum[1024];
     const uint32_t cols = p.P + 1;
     const uint32_t C = 1024 / cols; // >= 3
@@ -173,6 +176,7 @@ __device__ __forceinline__ void copy_record(uint8_t *dst, const uint8_t *src, ui
 
 __global__ __launch_bounds__(GEN_THREADS) void k_gen_scatter(GenParams p)
 {
+    if (p.gate && p.ctrl->head.fallback == 0) return;
     __shared__ uint32_t wtot[GEN_WAVES][MGS_MAX_RANKS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t tile = blockIdx.x;
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_gen_scatter(GenParams p)
 // One block.  Everything before the cut index counts; the rest is ignored.
 __global__ __launch_bounds__(GEN_THREADS) void k_gen_finalize(GenParams p)
 {
+    if (p.gate && p.ctrl->head.fallback == 0) return;
     __shared__ unsigned long long part[MGS_MAX_RANKS + 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t cols = p.P + 1;

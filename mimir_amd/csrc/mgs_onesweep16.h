@@ -75,6 +75,7 @@ struct OsParams {
     unsigned long long *status; // [ntiles][P]
     unsigned long long *agg16;  // [ntiles][1 << lpt_log]: 16-bit counts, four per word (windowed scan only)
     uint32_t lpt_log;           // log2 of the words per tile in agg16
+    uint32_t unit_shift;        // log2 of the bytes one counted unit stands for (4: 16-byte records, 0: bytes)
     uint8_t *dest_out;          // optional
     Ctrl *ctrl;
 };

@@ -49,9 +49,16 @@ __device__ __forceinline__ void os_publish_agg16(const OsParams &p, uint32_t til
 // The windowed chained scan for `tile` (> 0), run by one whole wave.  Returns,
 // in lanes b < P, the number of records of destination b in all earlier tiles
 // plus the initial fill.
-template <int VAR, int LOOK>
+struct OsNoop {
+    __device__ void operator()() const {}
+};
+
+// `between` runs once, after the first poll's loads have been issued and before
+// their results are used (a caller with other duties while the poll is in flight).
+template <int VAR, int LOOK, class Between = OsNoop>
 __device__ __forceinline__ unsigned long long os_window_walk(const OsParams &p, uint32_t tile, int lane,
-                                                             OsWalkStats *ws = nullptr)
+                                                             OsWalkStats *ws = nullptr,
+                                                             Between between = Between())
 {
     const uint32_t P = p.P;
     // counts: lane = (j, g): predecessor slot j of a load, word g of its row
@@ -72,7 +79,7 @@ __device__ __forceinline__ unsigned long long os_window_walk(const OsParams &p, 
     unsigned long long base = 0;
     int64_t look = (int64_t) tile - 1; // nearest predecessor not yet accounted for
     uint32_t cstar = 0;
-    bool done = false;
+    bool done = false, first_poll = true;
     uint32_t idle = 0, st_polls = 0, st_idle = 0;
     unsigned long long st_t0 = 0;
     if (VAR & OSV_STATS) st_t0 = __builtin_readcyclecounter();
@@ -97,11 +104,15 @@ __device__ __forceinline__ unsigned long long os_window_walk(const OsParams &p, 
         unsigned long long cv;
         if (!bin_ok) cv = OS_FLAG_INCL;
         else if (tb >= 0) cv = os_load_status(p.status + (uint64_t) tb * P + b);
-        else cv = OS_FLAG_INCL | (unsigned long long) (p.ctrl->head.part_init[b] >> 4);
+        else cv = OS_FLAG_INCL | (unsigned long long) (p.ctrl->head.part_init[b] >> p.unit_shift);
         // ... the nearest predecessors last: they published their counts only moments
         // ago, and every bit of time makes it likelier that this load sees them
         const int64_t t0 = look - (int64_t) j;
         v[0] = (t0 >= 0) ? os_load_status(p.agg16 + (uint64_t) t0 * lpt + g) : OS_AGG16_ONES;
+        if (first_poll) {
+            between();
+            first_poll = false;
+        }
 
         // first predecessor beyond the nearest load whose counts are not published yet
         uint32_t far_invalid = window;

@@ -264,6 +264,123 @@ def test_generic_equals_onesweep_on_16B(oracle):
         assert (na, nb) == ("generic", "onesweep16") and a.next == b.next
 
 
+# ---- byte-granular one-sweep kernel: variable width and short fixed widths -----------
+
+@pytest.mark.parametrize("P,rank", [(1, -1), (1, 0), (2, 0), (3, 1), (4, 3), (7, -1), (8, 5), (8, -1),
+                                    (16, 9), (33, 32), (63, 1), (64, -1)])
+def test_onesweepv_words(oracle, P, rank):
+    n = 30000
+    blob, offs, lay = datagen.word_records(n, n_unique=1000, alpha=0.5, len_mean=5, seed=44)
+    got, name = run_and_compare(oracle, blob, offs, lay, n, P, rank, int(offs[-1]), capi.ALGO_ONESWEEPV)
+    assert name == "onesweepv" and got.next == n
+
+
+def test_onesweepv_round_cuts_and_starts(oracle):
+    n = 25000
+    blob, offs, lay = datagen.word_records(n, n_unique=5000, alpha=1.0, len_mean=8, len_sd=2.5, seed=4)
+    for buf in (64, 1000, 4096, 65536):
+        got, name = run_and_compare(oracle, blob, offs, lay, n, 8, 2, buf, capi.ALGO_ONESWEEPV)
+        assert got.next < n and name == "onesweepv"
+    for start in (1, 1791, 1792, 12345, n - 1, n):
+        _, name = run_and_compare(oracle, blob, offs, lay, n, 8, 2, 4096, capi.ALGO_ONESWEEPV, start=start)
+    # a record larger than an empty partition is an error, as in the reference
+    # (src/collectiveshuffler.h:156-159)
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    pk = DevicePacker(_layouts(lay)[0], 8, 2, 8, n)
+    d_blob = torch.from_numpy(np.ascontiguousarray(blob)).cuda()
+    d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+    local = torch.empty(len(blob), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(capi.MgsError) as ei:
+        pk.pack(d_blob, n, pk.new_send_image(), rec_off=d_off, local_out=local, algo=capi.ALGO_ONESWEEPV)
+    assert ei.value.status == capi.ERR_RECORD_SIZE
+    pk.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 447, 448, 1791, 1792, 1793, 3584, 100000])
+def test_onesweepv_ragged_sizes(oracle, n):
+    blob, offs, lay = datagen.word_records(n, n_unique=300, alpha=0.8, len_mean=6, len_sd=2, seed=n)
+    got, name = run_and_compare(oracle, blob, offs, lay, n, 8, 3, int(offs[-1]), capi.ALGO_ONESWEEPV)
+    assert name == "onesweepv" and got.next == n
+
+
+def test_onesweepv_unaligned_blob(oracle):
+    """The record stream may start at any byte address."""
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    n = 20000
+    blob, offs, lay = datagen.word_records(n, n_unique=500, alpha=0.5, len_mean=5, len_sd=1.5, seed=9)
+    glay, olay = _layouts(lay)
+    want = oracle.pack_round(olay, blob, offs, n, 0, 8, -1, int(offs[-1]))
+    for shift in (1, 3, 7, 15):
+        buf = torch.zeros(len(blob) + 64, dtype=torch.uint8, device="cuda:0")
+        view = buf[shift:shift + len(blob)]
+        view.copy_(torch.from_numpy(np.ascontiguousarray(blob)))
+        d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+        pk = DevicePacker(glay, 8, -1, int(offs[-1]), n)
+        image = pk.new_send_image()
+        got = pk.pack(view, n, image, rec_off=d_off, algo=capi.ALGO_ONESWEEPV)
+        assert pk.last_algo() == "onesweepv"
+        assert got.send_offset.tolist() == want["send_offset"].tolist()
+        img = image.cpu().numpy()
+        for p in range(8):
+            so = int(want["send_offset"][p])
+            assert np.array_equal(img[p * int(offs[-1]):p * int(offs[-1]) + so], want["partitions"][p])
+        pk.close()
+
+
+@pytest.mark.parametrize("level", [1, 4, 7, 9, 11])
+def test_onesweepv_octant_levels(oracle, level):
+    """Fixed widths other than 16 bytes (level+8 <= 19), unaligned records."""
+    n = 20000
+    blob, _, lay = datagen.octree_records(n, level=level, seed=level)
+    _, name = run_and_compare(oracle, blob, None, lay, n, 8, 4, (level + 8) * n, capi.ALGO_ONESWEEPV)
+    assert name == "onesweepv"
+    run_and_compare(oracle, blob, None, lay, n, 8, 4, (level + 8) * 333, capi.ALGO_ONESWEEPV)
+
+
+def test_onesweepv_string_values_and_join(oracle):
+    rng = np.random.default_rng(3)
+    recs, offs = [], [0]
+    for _ in range(6000):
+        k = bytes(rng.integers(97, 123, size=rng.integers(1, 8), dtype=np.uint8)) + b"\0"
+        v = bytes(rng.integers(65, 91, size=rng.integers(0, 6), dtype=np.uint8)) + b"\0"
+        recs.append(k + v)
+        offs.append(offs[-1] + len(k) + len(v))
+    blob = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    offs = np.array(offs, dtype=np.uint64)
+    lay = (capi.KEY_CSTR, 0, capi.VAL_CSTR, 0)
+    _, name = run_and_compare(oracle, blob, offs, lay, 6000, 5, 3, int(offs[-1]), capi.ALGO_ONESWEEPV)
+    assert name == "onesweepv"
+    blob, offs, lay = datagen.join_records(20000, n_unique=2000, alpha=1.0, len_mean=2, len_sd=0.5, seed=45)
+    _, name = run_and_compare(oracle, blob, offs, lay, 20000, 4, 2, int(offs[-1]), capi.ALGO_ONESWEEPV)
+    assert name == "onesweepv"
+
+
+def test_onesweepv_falls_back_on_long_records(oracle):
+    """A tile whose records do not fit the LDS staging buffer: the call is served
+    by the generic path, decided on the device."""
+    rng = np.random.default_rng(1)
+    vocab = [bytes(rng.integers(97, 123, size=L, dtype=np.uint8)) for L in
+             [1, 2, 3, 11, 12, 13, 23, 24, 25, 100, 500, 1023]]
+    ranks = rng.integers(0, len(vocab), size=5000)
+    blob, offs, lay = datagen.word_records_from(vocab, ranks)
+    _, name = run_and_compare(oracle, blob, offs, lay, 5000, 8, 0, int(offs[-1]), capi.ALGO_ONESWEEPV)
+    assert name == "generic"
+    _, name = run_and_compare(oracle, blob, offs, lay, 5000, 8, 0, 3000, capi.ALGO_AUTO)
+    assert name == "generic"
+
+
+def test_onesweepv_skewed_keys(oracle):
+    """Every record to one destination, and a Zipf-heavy vocabulary."""
+    n = 20000
+    blob, offs, lay = datagen.word_records_from([b"same"], np.zeros(n, dtype=np.int64))
+    run_and_compare(oracle, blob, offs, lay, n, 8, -1, int(offs[-1]), capi.ALGO_ONESWEEPV)
+    run_and_compare(oracle, blob, offs, lay, n, 8, -1, 9000, capi.ALGO_ONESWEEPV)
+    blob, offs, lay = datagen.word_records(n, n_unique=50, alpha=2.0, len_mean=4, seed=7)
+    run_and_compare(oracle, blob, offs, lay, n, 8, 6, int(offs[-1]), capi.ALGO_ONESWEEPV)
+
+
 def test_window_limit_max_records(oracle):
     """A call looks at max_records records at most."""
     n = 10000
