@@ -73,10 +73,12 @@ enum {
                               fixed-width records, nranks <= 64               */
     MGS_ALGO_ONESWEEPV = 3  /* single-pass chained-scan kernel for
                               byte-granular records: variable width, or fixed
-                              widths up to 19 bytes; nranks <= 64 (63 with a
-                              local rank).  Variable-width batches whose
-                              records are too long for its LDS staging fall
-                              back to GENERIC inside the call                 */
+                              widths up to 79 bytes; nranks <= 64 (63 with a
+                              local rank).  A variable-width batch whose
+                              records are too long for the LDS staging of the
+                              tile in use falls back to GENERIC inside the
+                              call; the tile follows the record length seen in
+                              the handle's earlier calls                      */
 };
 
 typedef struct mgs_desc {

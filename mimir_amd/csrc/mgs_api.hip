@@ -137,6 +137,8 @@ struct mgs_handle {
     unsigned long long *d_agg16 = nullptr;
     size_t status_bytes = 0, agg16_bytes = 0;
     bool pending_osv = false; // the byte-granular one-sweep path was enqueued (may have fallen back)
+    int ov_k = 4;             // records per worker lane for variable-width input, adapted call by call
+    int pending_ov_k = 4;
     // call in flight
     bool pending = false;
     hipStream_t pending_stream = nullptr;
@@ -352,7 +354,17 @@ static int os16_min_tile()
 }
 
 // The byte-granular one-sweep kernel: 512 threads, 4 records per worker lane.
-constexpr int kOvThreads = 512, kOvK = 4, kOvTile = (kOvThreads / 64 - 1) * 64 * kOvK;
+// Tile = 448 worker lanes x K records; K = 4, 2 or 1 by record length (a tile's bytes must
+// fit the LDS staging buffer).
+constexpr int kOvThreads = 512, kOvLanes = (kOvThreads / 64 - 1) * 64;
+static int ov_tile(int k) { return kOvLanes * k; }
+// largest K whose tile of `bytes_per_record`-byte records fits, 0 if none
+static int ov_pick_k(double bytes_per_record)
+{
+    for (int k = 4; k >= 1; k >>= 1)
+        if ((double) ov_tile(k) * bytes_per_record + 15.0 <= (double) OV_IN_BYTES) return k;
+    return 0;
+}
 
 int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
                           uint64_t n_end, uint64_t start, const int64_t *init_offset,
@@ -418,13 +430,14 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
     // byte-granular one-sweep: chain columns = P (+1 for the local record count) <= 64, and for
     // fixed widths a tile that fits the LDS staging buffer (variable widths are checked on the device)
     const bool ov_ok = P + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
-                       && (h->fixed_len == 0
-                           || (uint64_t) kOvTile * h->fixed_len + 15 <= (uint64_t) OV_IN_BYTES);
+                       && (h->fixed_len == 0 || ov_pick_k((double) h->fixed_len) != 0);
+    // variable width: K follows the record length seen in earlier calls (mgs_pack_result)
+    const int ov_k = h->fixed_len ? ov_pick_k((double) h->fixed_len) : h->ov_k;
     if (algo == MGS_ALGO_AUTO)
         algo = os_ok ? MGS_ALGO_ONESWEEP16 : (ov_ok ? MGS_ALGO_ONESWEEPV : MGS_ALGO_GENERIC);
     if (algo == MGS_ALGO_ONESWEEPV && !ov_ok) {
         h->err = "mgs_pack_device: ONESWEEPV needs nranks (+1 with a local rank) <= 64 and, for fixed "
-                 "widths, records of at most 19 bytes";
+                 "widths, records of at most 79 bytes";
         return MGS_ERR_ARG;
     }
     if (algo == MGS_ALGO_ONESWEEP16 && !os_ok) {
@@ -505,6 +518,7 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         h->pending_osv = osv;
         if (osv) {
             const int columns = P + (D.rank >= 0 ? 1 : 0);
+            const int kOvTile = ov_tile(ov_k);
             int rc = ensure_onesweep_scratch(h, kOvTile, columns);
             if (rc) return rc;
             OvParams q;
@@ -539,7 +553,17 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
                 hipLaunchKernelGGL(k_osv_check, dim3((c.ntiles + 255) / 256), dim3(256), 0, stream, q);
             const uint32_t grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2));
             MGS_HIP(h, hipEventRecord(h->ev0, stream));
-            hipLaunchKernelGGL((k_onesweepv<kOvThreads, kOvK, 0, 4, 8>), dim3(grid), dim3(kOvThreads), 0, stream, q);
+            const mgs_layout &L = D.layout;
+            const int lm = (L.val_kind == MGS_VAL_CSTR) ? 0 : (L.key_kind == MGS_KEY_CSTR ? 1 : 2);
+            typedef void (*OvKernel)(OvParams);
+#define OVK(K, V) {k_onesweepv<kOvThreads, K, V, 4, 8, 0>, k_onesweepv<kOvThreads, K, V, 4, 8, 1>, \
+                   k_onesweepv<kOvThreads, K, V, 4, 8, 2>}
+            static const OvKernel kernels[4][3] = {OVK(1, 0), OVK(2, 0), OVK(4, 0), OVK(4, OSV_STATS)};
+#undef OVK
+            // MGS_OSV_STATS: diagnostic build (K = 4 only), per-phase cycle counts in Ctrl::head.stats
+            const int ki = ov_k == 1 ? 0 : (ov_k == 2 ? 1 : (getenv("MGS_OSV_STATS") ? 3 : 2));
+            hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
+            h->pending_ov_k = ov_k;
             if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
             hipLaunchKernelGGL(k_osv_finalize, dim3(1), dim3(64), 0, stream, q);
             h->last_algo = "onesweepv";
@@ -612,6 +636,21 @@ int mgs_pack_result(mgs_handle *h, mgs_round *out)
     }
     *out = h->h_ctrl->result;
     for (int b = P; b < MGS_MAX_RANKS; b++) out->send_offset[b] = 0;
+    if (h->fixed_len == 0) {
+        // Variable width: pick the next call's tile from this call's record length
+        // (a quarter of head-room: lengths vary from tile to tile); after a fall-back
+        // with nothing learnt, halve it.
+        const uint64_t recs = out->next - h->pending_start;
+        int64_t bytes = out->local_bytes;
+        for (int b = 0; b < P; b++) bytes += out->send_offset[b] - h->pending_init[b];
+        if (recs > 0 && bytes > 0) {
+            const int k = ov_pick_k(1.25 * (double) bytes / (double) recs);
+            h->ov_k = k ? k : 1;
+        }
+        else if (h->pending_osv && h->h_ctrl->head.fallback != 0 && h->ov_k > 1) {
+            h->ov_k /= 2;
+        }
+    }
     return MGS_OK;
 }
 

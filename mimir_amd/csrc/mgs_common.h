@@ -214,13 +214,18 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
                                      __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive
+// moves (no LDS traffic): shifts by 1, 2, 4, 8 inside each row of 16 lanes,
+// then the last lane of row 0/2 into row 1/3, then lane 31 into rows 2-3.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
+    (void) lane;
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false); // row_bcast:15
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); // row_bcast:31
     return v;
 }
 

@@ -144,6 +144,24 @@ __device__ __forceinline__ void ov_copy_lds(uint8_t *dst, const uint8_t *src, ui
     if (len & 1) dst[j] = src[j];
 }
 
+// 16 bytes of LDS at any alignment.  An LDS access that is not aligned to its
+// size runs at a fifth of the speed, so read the two aligned 16-byte blocks
+// around them and funnel-shift: dword select by bits 2-3 of the offset, then bytes.
+// `base` is 16-byte aligned; up to base[(off & ~15) + 31] is read.
+__device__ __forceinline__ uint4 ov_lds_read16(const uint8_t *base, uint32_t off)
+{
+    const uint4 lo4 = *reinterpret_cast<const uint4 *>(base + (off & ~15u));
+    const uint4 hi4 = *reinterpret_cast<const uint4 *>(base + (off & ~15u) + 16);
+    const bool q2 = (off & 8u) != 0, q1 = (off & 4u) != 0;
+    const uint32_t x0 = q2 ? lo4.z : lo4.x, x1 = q2 ? lo4.w : lo4.y, x2 = q2 ? hi4.x : lo4.z;
+    const uint32_t x3 = q2 ? hi4.y : lo4.w, x4 = q2 ? hi4.z : hi4.x, x5 = q2 ? hi4.w : hi4.y;
+    const uint32_t y0 = q1 ? x1 : x0, y1 = q1 ? x2 : x1, y2 = q1 ? x3 : x2;
+    const uint32_t y3 = q1 ? x4 : x3, y4 = q1 ? x5 : x4;
+    const uint32_t r = off & 3u;
+    return make_uint4(__builtin_amdgcn_alignbyte(y1, y0, r), __builtin_amdgcn_alignbyte(y2, y1, r),
+                      __builtin_amdgcn_alignbyte(y3, y2, r), __builtin_amdgcn_alignbyte(y4, y3, r));
+}
+
 // The workgroup barrier without the wait for outstanding memory operations
 // that the compiler puts in front of the builtin: the scan wave crosses the
 // workers' staging barriers with its poll still in flight.
@@ -165,7 +183,10 @@ __global__ void k_osv_check(OvParams q)
         __hip_atomic_store(&q.os.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int THREADS, int K, int VAR, int MINW, int LOOK>
+// LM (layout mode) spares the per-record layout decisions: 1 = string key(s) and a
+// fixed-width or absent value (key = the record minus the value, ends with a NUL);
+// 2 = fixed-width key and a fixed-width or absent value; 0 = any layout.
+template <int THREADS, int K, int VAR, int MINW, int LOOK, int LM>
 __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
 {
     const OsParams &p = q.os;
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
     __shared__ uint32_t dstart2[2 * OS_MAXP];        // first image byte of dest, two tiles
     __shared__ unsigned long long gaddr2[2 * OS_MAXP]; // global address of the run's first byte
     __shared__ uint32_t nbytes2[2 * OS_MAXP];          // bytes of the run to store (clipped)
-    __shared__ uint32_t cstart2[2 * (OS_MAXP + 1)];    // first chunk of dest's run (+ total)
+    __shared__ uint32_t cstart2[2 * (OS_MAXP + 1)];    // first store unit of dest's run (+ total)
     __shared__ volatile uint32_t misc[4];              // [0] first tile, [1] second tile / tile after next
     __shared__ uint32_t arrive[2];
 
@@ -246,18 +267,19 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
                 else atomicMin(&p.ctrl->head.cut_tile, tile);
             }
             const unsigned long long G = my_base + acc;
+            // work units of the store: (destination, block of 64 chunks of its run)
             const uint32_t nch = nb ? (uint32_t) (((G & 15ull) + nb + 15ull) >> 4) : 0u;
-            const uint32_t cincl = wave_incl_scan_u32(nch, lane);
+            const uint32_t units = (nch + 63u) >> 6;
+            const uint32_t uincl = wave_incl_scan_u32(units, lane);
             gaddr2[par * OS_MAXP + lane] = G;
             nbytes2[par * OS_MAXP + lane] = nb;
-            cstart2[par * (OS_MAXP + 1) + lane] = cincl - nch;
-            if (lane == 63) cstart2[par * (OS_MAXP + 1) + OS_MAXP] = cincl;
+            cstart2[par * (OS_MAXP + 1) + lane] = uincl - units;
+            if (lane == 63) cstart2[par * (OS_MAXP + 1) + OS_MAXP] = uincl;
             tile = next;
             next = next2;
             par ^= 1;
         }
         __syncthreads(); // matches the workers' last barrier
-        if ((VAR & OSV_STATS) && lane == 0) ws.flush(p.ctrl);
         return;
     }
 
@@ -267,14 +289,37 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
 
     // Fetch the offsets of a tile's records: absolute byte offsets of records
     // wt*K .. wt*K+K (K+1 values), and the tile's span.
-    auto fetch_offsets = [&](uint32_t t, uint64_t (&o)[K + 1], uint64_t &s, uint64_t &e) {
+    // A zero the compiler cannot see through: an index that is the same in every lane
+    // would be fetched with a scalar load, and scalar loads share their completion
+    // counter with LDS, out of order -- every later wait for an LDS access would then
+    // also wait out the round trip to memory.
+    uint32_t vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    // Offsets of a tile's records as fetched: K+1 record boundaries of this lane plus the
+    // span's two ends, as 32-bit values relative to `base` (the offset array's own values
+    // with base 0, or multiples of the fixed width with base = the tile's first byte).
+    // Nothing is computed from the loaded values here, so the loads stay in flight.
+    struct Offsets {
+        uint64_t base;
+        uint32_t rec[K + 1], s, e;
+    };
+    auto fetch_offsets = [&](uint32_t t, Offsets &f) {
         const uint64_t i0 = (uint64_t) t * T, i1 = min(q.n, i0 + T);
-        s = ov_offset(q, i0);
-        e = ov_offset(q, i1);
+        if (q.rec_off) {
+            const uint32_t *ro = q.rec_off + q.first;
+            f.base = 0;
+            f.s = ro[i0 + vzero];
+            f.e = ro[i1 + vzero];
 #pragma unroll
-        for (int k = 0; k <= K; k++) {
-            const uint64_t i = min(i1, i0 + (uint64_t) wt * K + k);
-            o[k] = ov_offset(q, i);
+            for (int k = 0; k <= K; k++) f.rec[k] = ro[min(i1, i0 + (uint64_t) wt * K + k)];
+        }
+        else {
+            f.base = (q.first + i0) * (uint64_t) q.fixed_len;
+            f.s = 0;
+            f.e = (uint32_t) (i1 - i0) * q.fixed_len;
+#pragma unroll
+            for (int k = 0; k <= K; k++)
+                f.rec[k] = (uint32_t) (min(i1, i0 + (uint64_t) wt * K + k) - i0) * q.fixed_len;
         }
     };
     // Issue the 16-byte loads of the span [s, e) (aligned down to 16 bytes).
@@ -296,106 +341,210 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
             if (c < nch) reinterpret_cast<uint4 *>(sin)[c] = ch[j];
         }
     };
-    auto set_records = [&](const uint64_t (&o)[K + 1], uint64_t s, uint64_t e) {
-        const uint32_t shift = (uint32_t) (((uintptr_t) q.blob + s) & 15u);
-        const uint32_t span = (uint32_t) (e - s) + shift;
+    auto set_records = [&](const Offsets &f) {
+        const uint32_t shift = (uint32_t) (((uintptr_t) q.blob + f.base + f.s) & 15u);
+        const uint64_t span = (uint64_t) (f.e - f.s) + shift;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const uint64_t l64 = o[k + 1] - o[k];
-            const uint64_t r64 = o[k] - s + shift;
-            lo[k] = (uint32_t) r64;
-            len[k] = (uint32_t) l64;
-            if (l64 == 0) continue; // past the end of the call
-            if (l64 > GEN_MAX_RECORD || o[k] < s || r64 + l64 > span) {
+            const uint32_t l = f.rec[k + 1] - f.rec[k]; // wraps to a huge value when not monotonic
+            const uint32_t r = f.rec[k] - f.s;
+            lo[k] = r + shift;
+            len[k] = l;
+            if (l == 0) continue; // past the end of the call
+            if (l > GEN_MAX_RECORD || f.rec[k] < f.s || (uint64_t) r + shift + l > span) {
                 raise_error(p.ctrl, MGS_ERR_MALFORMED);
                 len[k] = 0;
             }
         }
     };
-    // Stream out the image of a tile (parity pr).
+    // Stream out the image of a tile (parity pr).  A wave takes one unit at a time: 64
+    // consecutive 16-byte chunks of one destination's run, so everything but the chunk
+    // index is the same in all its lanes.
     auto store_image = [&](int pr) {
-        const uint32_t *cstart = cstart2 + pr * (OS_MAXP + 1);
-        const uint32_t total = cstart[OS_MAXP];
-        for (uint32_t c = (uint32_t) wt; c < total; c += WT) {
-            uint32_t b = 0;
-#pragma unroll
-            for (uint32_t step = OS_MAXP / 2; step > 0; step >>= 1)
-                if (cstart[b + step] <= c) b += step;
+        const uint32_t *ustart = cstart2 + pr * (OS_MAXP + 1);
+        const uint32_t utotal = ustart[OS_MAXP];
+        const uint32_t my_ustart = ustart[lane]; // lane = destination; non-decreasing, total from P on
+        for (uint32_t u = (uint32_t) w; u < utotal; u += WORKERS) {
+            const uint32_t b = (uint32_t) __popcll(__ballot(my_ustart <= u)) - 1u; // last dest starting at or before u
+            const uint32_t u0 = (uint32_t) __builtin_amdgcn_readlane((int) my_ustart, (int) b);
             const unsigned long long G = gaddr2[pr * OS_MAXP + b];
             const uint32_t nb = nbytes2[pr * OS_MAXP + b];
-            const uint8_t *src0 = sout + dstart2[pr * OS_MAXP + b]; // image byte of global byte G
-            const unsigned long long g0 = (G & ~15ull) + ((unsigned long long) (c - cstart[b]) << 4);
+            const uint32_t ds = dstart2[pr * OS_MAXP + b]; // image byte of global byte G
+            const uint32_t nch = (uint32_t) (((G & 15ull) + nb + 15ull) >> 4);
+            const uint32_t cb = (u - u0) * 64u + (uint32_t) lane;
+            if (cb >= nch) continue;
+            const unsigned long long g0 = (G & ~15ull) + ((unsigned long long) cb << 4);
             if (g0 >= G && g0 + 16 <= G + nb) {
-                const OvU128 v = *reinterpret_cast<const OvU128 *>(src0 + (g0 - G));
-                *reinterpret_cast<uint4 *>(g0) = make_uint4(v.x, v.y, v.z, v.w);
+                const uint4 val = ov_lds_read16(sout, ds + (uint32_t) (g0 - G));
+                if (VAR & OSV_NT_STORE) // timing experiment: no global store
+                    asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));
+                else
+                    *reinterpret_cast<uint4 *>(g0) = val;
             }
-            else {
-                const unsigned long long ga = g0 > G ? g0 : G;
+            else if (!(VAR & OSV_NT_LOAD)) { // (timing experiment: partial chunks skipped)
+                // partial chunk at an end of the run: naturally aligned pieces, growing
+                // from the first byte, then shrinking towards the last
+                const uint8_t *src0 = sout + ds;
+                unsigned long long ga = g0 > G ? g0 : G;
                 const unsigned long long gb = g0 + 16 < G + nb ? g0 + 16 : G + nb;
-                for (unsigned long long g = ga; g < gb; g++)
-                    *reinterpret_cast<uint8_t *>(g) = src0[g - G];
+                if ((ga & 1) && ga + 1 <= gb) {
+                    *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
+                    ga += 1;
+                }
+                if ((ga & 2) && ga + 2 <= gb) {
+                    *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
+                    ga += 2;
+                }
+                if ((ga & 4) && ga + 4 <= gb) {
+                    *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
+                    ga += 4;
+                }
+                if (ga + 8 <= gb) {
+                    *reinterpret_cast<unsigned long long *>(ga) =
+                        reinterpret_cast<const OvU64 *>(src0 + (ga - G))->v;
+                    ga += 8;
+                }
+                if (ga + 4 <= gb) {
+                    *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
+                    ga += 4;
+                }
+                if (ga + 2 <= gb) {
+                    *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
+                    ga += 2;
+                }
+                if (ga + 1 <= gb) *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
             }
         }
     };
 
+    // offsets of the tile after the current one: fetched one whole trip before its bytes,
+    // so that neither of the two dependent round trips is waited for
+    Offsets fn;
+    fn.base = 0;
+    fn.s = fn.e = 0;
     {
         // first tile: offsets, then bytes, then park them
-        uint64_t o[K + 1], s = 0, e = 0;
+        Offsets f0;
         uint4 ch[CPT];
         if (tile < p.ntiles) {
-            fetch_offsets(tile, o, s, e);
-            fetch_chunks(s, e, ch);
-            park_chunks(s, e, ch);
-            set_records(o, s, e);
+            fetch_offsets(tile, f0);
+            if (next < p.ntiles) fetch_offsets(next, fn);
+            fetch_chunks(f0.base + f0.s, f0.base + f0.e, ch);
+            park_chunks(f0.base + f0.s, f0.base + f0.e, ch);
+            set_records(f0);
         }
         __syncthreads();
     }
     bool have_prev = false;
+    // diagnostic build: cycles of worker wave 0 per phase of the trip
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    if (VAR & OSV_STATS) tprev = __builtin_readcyclecounter();
+#define OV_PHASE(i)                                                      \
+    if (VAR & OSV_STATS) {                                               \
+        const unsigned long long tnow = __builtin_readcyclecounter();    \
+        ph[i] += tnow - tprev;                                           \
+        tprev = tnow;                                                    \
+    }
 
     while (tile < p.ntiles) {
         uint32_t *wc = wcnt + par * (WORKERS * OS_MAXP);
         // ---- hash: destination of each of this lane's records
-        uint32_t d[K];
+        uint32_t d[K], h[K];
+        const uint32_t vlen = (q.lay.val_kind == MGS_VAL_FIXED) ? (uint32_t) q.lay.val_bytes : 0u;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            d[k] = 0xFFu;
-            if (len[k] != 0) {
-                uint32_t klen = 0;
-                if (!ov_key_len(q.lay, sin + lo[k], len[k], klen)) {
-                    raise_error(p.ctrl, MGS_ERR_MALFORMED);
-                    len[k] = 0;
+            h[k] = 0;
+            if (len[k] == 0) continue;
+            const uint8_t *r = sin + lo[k];
+            uint32_t klen = 0;
+            bool ok;
+            if (LM == 1) {
+                klen = len[k] - vlen;
+                ok = len[k] > vlen;
+            }
+            else if (LM == 2) {
+                klen = (uint32_t) q.lay.key_bytes;
+                ok = klen <= len[k];
+            }
+            else {
+                ok = ov_key_len(q.lay, r, len[k], klen);
+            }
+            if (ok && klen <= 12) {
+                // the whole key is lookup3's tail: three words, masked to the key's bytes
+                const uint32_t w0 = reinterpret_cast<const OvU32 *>(r)->v;
+                const uint32_t w1 = reinterpret_cast<const OvU32 *>(r + 4)->v;
+                const uint32_t w2 = reinterpret_cast<const OvU32 *>(r + 8)->v;
+                const uint32_t m0 = klen >= 4 ? 0xFFFFFFFFu : ((1u << (8 * klen)) - 1u);
+                const uint32_t m1 = klen >= 8 ? 0xFFFFFFFFu : (klen > 4 ? ((1u << (8 * (klen - 4))) - 1u) : 0u);
+                const uint32_t m2 = klen >= 12 ? 0xFFFFFFFFu : (klen > 8 ? ((1u << (8 * (klen - 8))) - 1u) : 0u);
+                if (LM == 1) { // the key's last byte must be its NUL
+                    const uint32_t last = klen - 1;
+                    const uint32_t wl = last >= 8 ? w2 : (last >= 4 ? w1 : w0);
+                    ok = ((wl >> (8 * (last & 3u))) & 0xFFu) == 0;
                 }
-                else {
-                    d[k] = fastmod(ov_hash_lds(sin + lo[k], klen), p.fm);
-                    if (p.dest_out) p.dest_out[(uint64_t) tile * T + (uint64_t) wt * K + k] = (uint8_t) d[k];
-                }
+                uint32_t a, b, c;
+                a = b = c = 0xdeadbeefu + klen;
+                a += w0 & m0;
+                b += w1 & m1;
+                c += w2 & m2;
+                MGS_FINAL(a, b, c);
+                h[k] = c;
+            }
+            else if (ok) {
+                if (LM == 1) ok = r[klen - 1] == 0;
+                h[k] = ov_hash_lds(r, klen);
+            }
+            if (!ok) {
+                raise_error(p.ctrl, MGS_ERR_MALFORMED);
+                len[k] = 0;
             }
         }
-        // ---- rank: byte position of each record inside the wave's share of its destination
-        uint32_t pw[K];
+        if (p.fm.pow2) {
 #pragma unroll
-        for (int k = 0; k < K; k++) pw[k] = 0;
-        for (uint32_t b = 0; b < P; b++) {
+            for (int k = 0; k < K; k++) d[k] = len[k] ? fastmod_pow2(h[k], p.fm) : 0xFFu;
+        }
+        else {
+#pragma unroll
+            for (int k = 0; k < K; k++) d[k] = len[k] ? fastmod_magic(h[k], p.fm) : 0xFFu;
+        }
+        if (p.dest_out) {
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (len[k]) p.dest_out[(uint64_t) tile * T + (uint64_t) wt * K + k] = (uint8_t) d[k];
+        }
+        OV_PHASE(0)
+        // ---- rank: byte position of each record inside the wave's share of its destination.
+        // Two destinations share one scan: 16-bit fields (a wave's bytes fit: they are
+        // part of one staged span).
+        uint32_t pw[K], field[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            pw[k] = 0;
+            field[k] = len[k] << (16 * (d[k] & 1u)); // this record's bytes in its destination's field
+        }
+        for (uint32_t b2 = 0; b2 < (P + 1) / 2; b2++) {
             uint32_t mine = 0;
 #pragma unroll
-            for (int k = 0; k < K; k++) mine += (d[k] == b) ? len[k] : 0u;
+            for (int k = 0; k < K; k++) mine += ((d[k] >> 1) == b2) ? field[k] : 0u;
             const uint32_t incl = wave_incl_scan_u32(mine, lane);
             uint32_t run = incl - mine;
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                if (d[k] == b) {
-                    pw[k] = run;
-                    run += len[k];
+                if ((d[k] >> 1) == b2) {
+                    pw[k] = (run >> (16 * (d[k] & 1u))) & 0xffffu;
+                    run += field[k];
                 }
             }
-            if (lane == 63) wc[w * OS_MAXP + b] = incl;
+            if (lane == 63) {
+                wc[w * OS_MAXP + 2 * b2] = incl & 0xffffu;
+                wc[w * OS_MAXP + 2 * b2 + 1] = incl >> 16;
+            }
         }
         if (p.self >= 0) { // chain column P: records of the local-bypass destination
-            uint32_t mine = 0;
+            uint32_t cnt = 0;
 #pragma unroll
-            for (int k = 0; k < K; k++) mine += (d[k] == (uint32_t) p.self) ? 1u : 0u;
-            const uint32_t incl = wave_incl_scan_u32(mine, lane);
-            if (lane == 63) wc[w * OS_MAXP + P] = incl;
+            for (int k = 0; k < K; k++) cnt += (uint32_t) __popcll(__ballot(d[k] == (uint32_t) p.self));
+            if (lane == 63) wc[w * OS_MAXP + P] = cnt;
         }
         {
             // the last worker wave to get here publishes the tile's byte counts
@@ -412,11 +561,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
                 os_publish_agg16(p, tile, lane, tot_all);
             }
         }
+        OV_PHASE(1)
         __syncthreads(); // A: counts(tile) complete; tables of the previous tile are ready
-
-        // offsets of the next tile: in flight during the store
-        uint64_t o[K + 1], ns = 0, ne = 0;
-        if (next < p.ntiles) fetch_offsets(next, o, ns, ne);
+        OV_PHASE(2)
 
         uint32_t tot = 0, below = 0; // lane = destination
 #pragma unroll
@@ -430,21 +577,69 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
         wslot[w * OS_MAXP + lane] = first_byte + below;
         if (w == 0) dstart2[par * OS_MAXP + lane] = first_byte;
         if (have_prev) store_image(par ^ 1);
+        OV_PHASE(3)
         __syncthreads(); // B: the image is free
+        OV_PHASE(4)
         const uint32_t next2 = misc[1];
 
-        // bytes of the next tile: in flight during the reorder
+        // bytes of the next tile (its offsets arrived during the last trip) and offsets of
+        // the tile after it: in flight during the reorder
         uint4 ch[CPT];
-        if (next < p.ntiles) fetch_chunks(ns, ne, ch);
+        Offsets fn2;
+        fn2.base = 0;
+        fn2.s = fn2.e = 0;
+        if (next < p.ntiles) fetch_chunks(fn.base + fn.s, fn.base + fn.e, ch);
+        if (next2 < p.ntiles) fetch_offsets(next2, fn2);
+        {
+            // reorder: all reads first (the first 16 bytes of every record, and where it
+            // goes), then the writes -- pieces of 8/4/2/1 bytes out of registers
+            uint4 head[K];
+            uint32_t dst[K];
 #pragma unroll
-        for (int k = 0; k < K; k++)
-            if (len[k] != 0) ov_copy_lds(sout + wslot[w * OS_MAXP + d[k]] + pw[k], sin + lo[k], len[k]);
+            for (int k = 0; k < K; k++) {
+                head[k] = ov_lds_read16(sin, len[k] ? lo[k] : 0u);
+                dst[k] = wslot[w * OS_MAXP + (len[k] ? d[k] : 0u)] + pw[k];
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (len[k] == 0) continue;
+                uint8_t *o = sout + dst[k];
+                if (len[k] >= 16) { // the rest of a longer record follows below
+                    *reinterpret_cast<OvU128 *>(o) = OvU128{head[k].x, head[k].y, head[k].z, head[k].w};
+                    continue;
+                }
+                uint32_t a0 = head[k].x, a1 = head[k].y, a2 = head[k].z, a3 = head[k].w;
+                if (len[k] & 8u) {
+                    reinterpret_cast<OvU64 *>(o)->v = (unsigned long long) a0 | ((unsigned long long) a1 << 32);
+                    a0 = a2;
+                    a1 = a3;
+                    o += 8;
+                }
+                if (len[k] & 4u) {
+                    reinterpret_cast<OvU32 *>(o)->v = a0;
+                    a0 = a1;
+                    o += 4;
+                }
+                if (len[k] & 2u) {
+                    reinterpret_cast<OvU16 *>(o)->v = (uint16_t) a0;
+                    a0 >>= 16;
+                    o += 2;
+                }
+                if (len[k] & 1u) *o = (uint8_t) a0;
+            }
+            for (int k = 0; k < K; k++) // not unrolled: rare for short records
+                if (len[k] > 16) ov_copy_lds(sout + dst[k] + 16, sin + lo[k] + 16, len[k] - 16);
+        }
+        OV_PHASE(5)
         __syncthreads(); // C: the staging buffer is free
         if (next < p.ntiles) {
-            park_chunks(ns, ne, ch);
-            set_records(o, ns, ne);
+            park_chunks(fn.base + fn.s, fn.base + fn.e, ch);
+            set_records(fn);
         }
+        fn = fn2;
+        OV_PHASE(6)
         __syncthreads(); // D: the next tile is staged
+        OV_PHASE(7)
         have_prev = true;
         tile = next;
         next = next2;
@@ -452,6 +647,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
     }
     __syncthreads(); // tables of the last tile are ready
     if (have_prev) store_image(par ^ 1);
+    if ((VAR & OSV_STATS) && wt == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(&p.ctrl->head.stats[i], ph[i]);
+    }
+#undef OV_PHASE
 }
 
 // One wave.  send_offset[] / counts at the point where the round ended; when a

@@ -329,9 +329,9 @@ def test_onesweepv_unaligned_blob(oracle):
         pk.close()
 
 
-@pytest.mark.parametrize("level", [1, 4, 7, 9, 11])
+@pytest.mark.parametrize("level", [1, 4, 7, 9, 11, 12, 15])
 def test_onesweepv_octant_levels(oracle, level):
-    """Fixed widths other than 16 bytes (level+8 <= 19), unaligned records."""
+    """Fixed widths other than 16 bytes, unaligned records (4, 2 or 1 records per lane)."""
     n = 20000
     blob, _, lay = datagen.octree_records(n, level=level, seed=level)
     _, name = run_and_compare(oracle, blob, None, lay, n, 8, 4, (level + 8) * n, capi.ALGO_ONESWEEPV)
@@ -355,6 +355,36 @@ def test_onesweepv_string_values_and_join(oracle):
     blob, offs, lay = datagen.join_records(20000, n_unique=2000, alpha=1.0, len_mean=2, len_sd=0.5, seed=45)
     _, name = run_and_compare(oracle, blob, offs, lay, 20000, 4, 2, int(offs[-1]), capi.ALGO_ONESWEEPV)
     assert name == "onesweepv"
+
+
+def test_onesweepv_adapts_tile_to_record_length(oracle):
+    """Records too long for the default tile: the first call falls back, the next
+    calls on the same handle use a smaller tile.  Same bytes either way."""
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    n = 30000
+    blob, offs, lay = datagen.join_records(n, n_unique=2000, alpha=1.0, len_mean=14, len_sd=3, seed=46)
+    glay, olay = _layouts(lay)
+    total = int(offs[-1])
+    want = oracle.pack_round(olay, blob, offs, n, 0, 8, 2, total)
+    d_blob = torch.from_numpy(np.ascontiguousarray(blob)).cuda()
+    d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+    pk = DevicePacker(glay, 8, 2, total, n)
+    algos = []
+    for _ in range(3):
+        image = torch.full((8 * total,), 0xEE, dtype=torch.uint8, device="cuda:0")
+        local = torch.full((total,), 0xDD, dtype=torch.uint8, device="cuda:0")
+        got = pk.pack(d_blob, n, image, rec_off=d_off, local_out=local)
+        algos.append(pk.last_algo())
+        assert got.next == n and got.send_offset.tolist() == want["send_offset"].tolist()
+        assert got.local_records == want["local_records"] and got.local_bytes == want["local_bytes"]
+        img = image.cpu().numpy()
+        for p in range(8):
+            so = int(want["send_offset"][p])
+            assert np.array_equal(img[p * total:p * total + so], want["partitions"][p])
+        assert np.array_equal(local.cpu().numpy()[:got.local_bytes], want["local"])
+    assert algos[0] == "generic" and algos[1] == "onesweepv" and algos[2] == "onesweepv", algos
+    pk.close()
 
 
 def test_onesweepv_falls_back_on_long_records(oracle):
