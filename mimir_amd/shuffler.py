@@ -181,20 +181,40 @@ class GpuShuffler:
             d_off = torch.from_numpy(np.asarray(self._stage_off, dtype=np.uint32).view(np.int32)).to(self.dev)
         start = 0
         while start < n:
-            r = self.packer.pack(blob, n, self.send_image, start=start, rec_off=d_off,
-                                 init_offset=self.send_offset, local_out=self.local_out)
-            self.send_offset[:] = r.send_offset
+            image, offset = self._current_round()
+            r = self.packer.pack(blob, n, image, start=start, rec_off=d_off,
+                                 init_offset=offset, local_out=self.local_out)
+            offset[:] = r.send_offset
             self.kvcount += r.packed_records
             if r.local_bytes:  # out->write at emit time, src/collectiveshuffler.h:135-141
                 loc = self.local_out[:r.local_bytes].cpu().numpy()
-                self.out.write_records(loc, wire_offsets(self.layout, loc))
+                self._deliver(loc, self.shuffle_rank)
             if r.next < n:      # kv_to_bytes == -1: exchange, then retry (:148-160)
-                if r.next == start and not r.local_records and int(self.send_offset.sum()) == 0:
+                if r.next == start and not r.local_records and int(offset.sum()) == 0:
                     raise capi.MgsError(capi.ERR_RECORD_SIZE, "KV size is larger than buf_size")
-                self.exchange_kv()
+                self._round_full()
+            self._after_pack()
             start = r.next
         self._stage_off = [0]
         self._stage_used = 0
+
+    # hooks the non-blocking shuffler overrides
+    def _current_round(self):
+        return self.send_image, self.send_offset
+
+    def _round_full(self):
+        self.exchange_kv()
+
+    def _after_pack(self):
+        pass
+
+    def _deliver(self, blob, src):
+        """Hand wire-form records that came from rank `src` to the sink, in order."""
+        offs = wire_offsets(self.layout, blob)
+        if hasattr(self.out, "write_records_from"):
+            self.out.write_records_from(src, blob, offs)
+        else:
+            self.out.write_records(blob, offs)
 
     def exchange_kv(self):
         """src/collectiveshuffler.h:587-674."""
@@ -236,5 +256,236 @@ class GpuShuffler:
         self.done_flag = 1
         while True:
             self.exchange_kv()
+            if self.done_count >= self.shuffle_size:
+                break
+
+
+class _MsgBuf:
+    """ShuffleMsgBuf (src/nbcollectiveshuffler.h:22-34): one send image, one
+    receive image and the state of the exchange that uses them."""
+    START, PENDING, COMPLETE = 0, 1, 2
+
+    def __init__(self, P, buf_size, dev, xdev, host_exchange):
+        self.send_image = torch.empty(P * buf_size, dtype=torch.uint8, device=dev)
+        self.recv_image = torch.empty(P * buf_size, dtype=torch.uint8, device=xdev)
+        self.host_send = torch.empty(P * buf_size, dtype=torch.uint8) if host_exchange else None
+        self.send_offset = np.zeros(P, dtype=np.int64)
+        self.recv_count = None
+        self.token = 0
+        self.state = _MsgBuf.COMPLETE
+        self.send_bytes = 0
+        self.recv_bytes = 0
+        self.a2a_work = None    # counts all-to-all in flight (MPI_Ialltoall, :237-239)
+        self.a2a_in = None
+        self.a2a_out = None
+        self.a2av_works = None  # payload in flight (MPI_Ialltoallv, :347-351)
+
+
+class NBGpuShuffler(GpuShuffler):
+    """NBCollectiveShuffler (src/nbcollectiveshuffler.h): the same partition
+    image per buffer, but 2..5 buffers, so that the exchange of a full round
+    runs while the next round is being packed.  Counts travel on one process
+    group and payloads on another (the reference's two duplicated
+    communicators, :68-69), payloads strictly in token order (:318-359).
+
+    The order in which a rank's sink sees its own records and the records of
+    each peer is the same as with the blocking shuffler; how the streams of
+    different sources interleave depends on when exchanges complete, as in the
+    reference."""
+    MIN_SBUF_COUNT = 2  # src/config.cpp:20-21
+    MAX_SBUF_COUNT = 5
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if dist.is_initialized() and self.shuffle_size > 1:
+            ranks = ([dist.get_global_rank(self.group, r) for r in range(self.shuffle_size)]
+                     if self.group is not None else None)
+            self.a2a_group = dist.new_group(ranks)
+            self.a2av_group = dist.new_group(ranks)
+        else:
+            self.a2a_group = self.a2av_group = None
+
+    def open(self):
+        super().open()
+        self._xdev = self.recv_image.device
+        self.msg = []
+        self.cur_idx = 0
+        self.a2a_token = 0
+        self.a2av_token = 0
+        self.pending_msg = 0
+        self.round_log = []  # send_offset of every exchange started, in order (-1 = vote)
+        self._p2p_blocking = dist.is_initialized() and dist.get_backend(self.group) != "nccl"
+        for _ in range(self.MIN_SBUF_COUNT):
+            self._insert_comm_buffer()
+        return True
+
+    def _insert_comm_buffer(self):  # :426-449
+        self.msg.append(_MsgBuf(self.shuffle_size, self.buf_size, self.dev, self._xdev,
+                                self.host_exchange))
+
+    def _current_round(self):
+        m = self.msg[self.cur_idx]
+        return m.send_image, m.send_offset
+
+    def _round_full(self):
+        self.start_kv_exchange()
+
+    def _after_pack(self):
+        self.push_kv_exchange()  # after every record in the reference (:179)
+
+    def make_progress(self, issue_new=False):  # :185-189
+        self.flush()
+        if issue_new and self.pending_msg == 0:
+            self.start_kv_exchange()
+        self.push_kv_exchange()
+
+    def exchange_kv(self):
+        raise RuntimeError("the non-blocking shuffler has no blocking exchange")
+
+    # ---- :222-277 ----------------------------------------------------------------
+    def start_kv_exchange(self):
+        P = self.shuffle_size
+        m = self.msg[self.cur_idx]
+        if self.done_flag:
+            m.send_offset[:] = -1
+        else:
+            m.send_bytes += int(m.send_offset.sum())
+            self.send_bytes += int(m.send_offset.sum())
+        self.shuffle_times += 1
+        self.round_log.append(m.send_offset.copy())
+        if self.a2a_group is not None:
+            cdev = torch.device("cpu") if self._xdev.type == "cpu" else self.dev
+            m.a2a_in = torch.as_tensor(m.send_offset, dtype=torch.int64).to(cdev)
+            m.a2a_out = torch.empty_like(m.a2a_in)
+            m.a2a_work = dist.all_to_all_single(m.a2a_out, m.a2a_in, group=self.a2a_group,
+                                                async_op=True)
+        else:  # a single rank talks to itself
+            m.a2a_out = torch.as_tensor(m.send_offset.copy(), dtype=torch.int64)
+            m.a2a_work = None
+        m.recv_count = None
+        m.state = _MsgBuf.START
+        m.token = self.a2a_token
+        self.a2a_token += 1
+        self.pending_msg += 1
+        self.push_kv_exchange()
+        self.cur_idx = -1
+        for i, b in enumerate(self.msg):
+            if b.state == _MsgBuf.COMPLETE:
+                self.cur_idx = i
+                break
+        if self.cur_idx == -1:
+            if len(self.msg) < self.MAX_SBUF_COUNT:
+                self._insert_comm_buffer()
+                self.cur_idx = len(self.msg) - 1
+            else:
+                self.cur_idx = 0
+                while True:
+                    self.push_kv_exchange()
+                    if self.msg[self.cur_idx].state == _MsgBuf.COMPLETE:
+                        break
+                    self.cur_idx = (self.cur_idx + 1) % len(self.msg)
+
+    # ---- :279-387 ----------------------------------------------------------------
+    def push_kv_exchange(self):
+        P = self.shuffle_size
+        for m in self.msg:
+            if m.state == _MsgBuf.COMPLETE:
+                continue
+            if m.state == _MsgBuf.START:
+                if m.recv_count is None and (m.a2a_work is None or m.a2a_work.is_completed()):
+                    if m.a2a_work is not None:
+                        m.a2a_work.wait()
+                    rc = m.a2a_out.cpu().numpy().astype(np.int64)
+                    self.done_count = int((rc == -1).sum())
+                    m.recv_bytes += int(rc[rc != -1].sum())
+                    m.recv_count = rc
+                    m.a2a_work = None
+                if self.done_count == P and m.recv_count is not None:
+                    m.state = _MsgBuf.COMPLETE
+                    self.pending_msg -= 1
+                    self._reset(m)
+                    continue
+                if (m.token == self.a2av_token and m.recv_count is not None
+                        and self.done_count < P):
+                    m.send_offset[m.send_offset == -1] = 0
+                    m.recv_count[m.recv_count == -1] = 0
+                    self._start_payload(m)
+                    self.recv_bytes += int(m.recv_count.sum())
+                    m.state = _MsgBuf.PENDING
+                    self.a2av_token += 1
+            if m.state == _MsgBuf.PENDING:
+                # gloo's point-to-point requests only complete inside wait(): block there.
+                # Payloads are posted in token order on every rank, so this cannot deadlock;
+                # it only gives up the overlap, which matters on RCCL, where polling works.
+                if self._p2p_blocking or all(w.is_completed() for w in m.a2av_works):
+                    for w in m.a2av_works:
+                        w.wait()
+                    m.a2av_works = None
+                    self._save_data(m)
+                    self._reset(m)
+                    m.state = _MsgBuf.COMPLETE
+                    self.pending_msg -= 1
+
+    def _reset(self, m):
+        m.token = 0
+        m.send_bytes = 0
+        m.recv_bytes = 0
+        m.send_offset[:] = 0
+        m.recv_count = None
+
+    def _start_payload(self, m):
+        P, me, bs = self.shuffle_size, self.shuffle_rank, self.buf_size
+        if self.a2av_group is None:
+            m.a2av_works = []
+            return
+        if self.host_exchange:
+            for d in range(P):
+                so = int(m.send_offset[d])
+                if so:
+                    m.host_send[d * bs:d * bs + so].copy_(m.send_image[d * bs:d * bs + so])
+            src = m.host_send
+        else:
+            src = m.send_image
+            if self.dev.type == "cuda":
+                torch.cuda.current_stream(self.dev).synchronize()
+        ops, roff = [], 0
+        for peer in range(P):
+            rc = int(m.recv_count[peer])
+            if rc > 0 and peer != me:
+                ops.append(dist.P2POp(dist.irecv, m.recv_image[roff:roff + rc],
+                                      dist.get_global_rank(self.a2av_group, peer),
+                                      group=self.a2av_group))
+            roff += rc
+        for peer in range(P):
+            so = int(m.send_offset[peer])
+            if so > 0 and peer != me:
+                ops.append(dist.P2POp(dist.isend, src[peer * bs:peer * bs + so],
+                                      dist.get_global_rank(self.a2av_group, peer),
+                                      group=self.a2av_group))
+        m.a2av_works = dist.batch_isend_irecv(ops) if ops else []
+
+    def _save_data(self, m):  # :400-424
+        roff = 0
+        for src in range(self.shuffle_size):
+            rc = int(m.recv_count[src])
+            if rc:
+                self._deliver(m.recv_image[roff:roff + rc].cpu().numpy(), src)
+            roff += rc
+
+    def wait_all(self):  # :396-399
+        while self.pending_msg > 0:
+            self.push_kv_exchange()
+
+    def wait(self):  # :192-220
+        self.flush()
+        m = self.msg[self.cur_idx]
+        m.send_bytes += int(m.send_offset.sum())
+        if m.send_bytes > 0:
+            self.start_kv_exchange()
+        self.wait_all()
+        self.done_flag = 1
+        while True:
+            self.start_kv_exchange()
+            self.wait_all()
             if self.done_count >= self.shuffle_size:
                 break

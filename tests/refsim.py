@@ -60,6 +60,33 @@ def simulate_shuffle(orc, lay, streams, P, buf_size):
     return sinks, stats
 
 
+def simulate_streams(orc, lay, streams, P, buf_size):
+    """Per-source view of the same shuffle, for shufflers whose exchanges
+    complete asynchronously: per[r][src] = the records rank r receives from
+    rank src (src == r: its own local-bypass records), in order; rounds[r] =
+    the send_offset vector of each of rank r's rounds that carries data."""
+    olay = olayout(lay)
+    per = [[[] for _ in range(P)] for _ in range(P)]
+    rounds = [[] for _ in range(P)]
+    kvcount = [0] * P
+    for src in range(P):
+        blob, offs, n = streams[src]
+        start = 0
+        while True:
+            rd = orc.pack_round(olay, blob, offs, n, start, P, src, buf_size)
+            per[src][src].extend(split_records(orc, olay, rd["local"]))
+            for r in range(P):
+                if r != src:
+                    per[r][src].extend(split_records(orc, olay, rd["partitions"][r]))
+            if int(rd["send_offset"].sum()) > 0:
+                rounds[src].append(rd["send_offset"].tolist())
+            kvcount[src] += rd["packed_records"]
+            start = rd["next"]
+            if start >= n:
+                break
+    return per, rounds, kvcount
+
+
 class _Round:
     pass
 

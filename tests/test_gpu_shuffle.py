@@ -4,7 +4,7 @@ host copies of their partitions.  Every rank's sink must receive exactly what
 the reference's `out` would, in the same order."""
 import pytest
 
-from tests.test_shuffle_gloo import run_case
+from tests.test_shuffle_gloo import run_case, run_nb_case
 
 pytestmark = pytest.mark.gpu
 
@@ -20,3 +20,9 @@ def test_gpu_shuffle_default_geometry(oracle):
     # one data exchange, then the done vote
     run_case(oracle, 2, "u64", comm=64 << 20, use_gpu=True, min_rounds=1,
              counts=[600_000, 500_000])
+
+
+@pytest.mark.parametrize("P,kind", [(2, "words"), (3, "u64")])
+def test_gpu_nonblocking_shuffle(oracle, P, kind):
+    """NBCollectiveShuffler mirror over the real pack path."""
+    run_nb_case(oracle, P, kind, use_gpu=True)

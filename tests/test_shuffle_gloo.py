@@ -103,3 +103,77 @@ def test_shuffle_matches_reference_simulation(oracle, P, kind):
 def test_exchange_layout_two_ranks(oracle):
     """exchange_round alone: receive image = src-ordered concatenation."""
     run_case(oracle, 2, "words", comm=8192)
+
+
+# ---- the non-blocking shuffler (NBCollectiveShuffler mirror) --------------------------
+
+class _TaggedSink:
+    """Keeps what it is given per source rank."""
+
+    def __init__(self, P):
+        self.by_src = [[] for _ in range(P)]
+
+    def write_records_from(self, src, blob, rec_off):
+        b = blob.tobytes()
+        for i in range(len(rec_off) - 1):
+            self.by_src[src].append(b[int(rec_off[i]):int(rec_off[i + 1])])
+
+
+def _nb_worker(rank, P, port, kind, comm, outdir, counts, use_gpu=False):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=P)
+    try:
+        from mimir_amd.shuffler import NBGpuShuffler
+        n = counts[rank]
+        blob, offs, lay = make_stream(kind, rank, n)
+        sink = _TaggedSink(P)
+        sh = NBGpuShuffler(sink, lay, comm_buf_size=comm, stage_bytes=1 << 16,
+                           packer_factory=None if use_gpu else refsim.OraclePacker)
+        sh.open()
+        if offs is None:
+            offs = datagen.fixed_offsets(n, lay.fixed_len())
+        cuts = sorted(set([0, n // 7, n // 3, n // 2, n]))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            base = int(offs[a])
+            sh.write_records(blob[base:int(offs[b])], offs[a:b + 1] - offs[a])
+            sh.make_progress()
+        sh.close()
+        data_rounds = [r.tolist() for r in sh.round_log if int(r[0]) != -1 and int(r.sum()) > 0]
+        with open(os.path.join(outdir, f"rank{rank}.pkl"), "wb") as f:
+            pickle.dump({"by_src": sink.by_src, "kvcount": sh.get_record_count(),
+                         "send_bytes": sh.send_bytes, "recv_bytes": sh.recv_bytes,
+                         "rounds": data_rounds, "buffers": len(sh.msg)}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_nb_case(oracle, P, kind, use_gpu=False):
+    """Same rounds (bytes per destination, in order), same per-source record
+    sequences at every sink, same counters as the blocking shuffle; only the
+    interleaving of different sources is left to timing, as in the reference."""
+    counts = counts_for(P)
+    comm = 16384
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_nb_worker, args=(P, _free_port(), kind, comm, d, counts, use_gpu), nprocs=P, join=True)
+        got = [pickle.load(open(os.path.join(d, f"rank{r}.pkl"), "rb")) for r in range(P)]
+    streams, lay = [], None
+    for r in range(P):
+        blob, offs, lay = make_stream(kind, r, counts[r])
+        streams.append((blob, offs, counts[r]))
+    buf_size = capi.geometry(comm, P)[0]
+    per, rounds, kvcount = refsim.simulate_streams(oracle, lay, streams, P, buf_size)
+    assert max(len(x) for x in rounds) >= 3, "case too small to cut rounds"
+    for r in range(P):
+        for src in range(P):
+            assert got[r]["by_src"][src] == per[r][src], f"rank {r}: records from {src} differ"
+        assert got[r]["rounds"] == rounds[r]
+        assert got[r]["kvcount"] == kvcount[r]
+        assert got[r]["send_bytes"] == sum(sum(x) for x in rounds[r])
+        assert got[r]["recv_bytes"] == sum(len(b) for s in range(P) if s != r for b in per[r][s])
+        assert 2 <= got[r]["buffers"] <= 5
+
+
+@pytest.mark.parametrize("P,kind", [(2, "words"), (3, "u64"), (4, "join")])
+def test_nonblocking_shuffler_matches_reference_rounds(oracle, P, kind):
+    run_nb_case(oracle, P, kind)
