@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: device-resident hash-partition + pack of <u64,u64>
-records into 8 destination partitions (BASELINE.json configs[1]).
+records into 8 destination partitions (the 1e9-record fixed-width configuration).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--records R]
 

@@ -16,8 +16,7 @@
 // mimir_gpu, and talks to the outside world through `Exchange`, a two-call
 // transport (int all-to-all, byte all-to-all-v).  Inside Mimir one derives
 // from MIMIR_NS::BaseShuffler instead and implements Exchange with
-// MPI_Alltoall / MPI_Alltoallv on the shuffler's communicator; INTEGRATION.md
-// shows that variant.
+// MPI_Alltoall / MPI_Alltoallv on the shuffler's communicator.
 #ifndef MIMIR_GPU_SHUFFLER_HPP
 #define MIMIR_GPU_SHUFFLER_HPP
 
