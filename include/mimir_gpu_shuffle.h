@@ -186,6 +186,42 @@ const char *mgs_last_algo(const mgs_handle *h);
 /* The descriptor the handle was created with. */
 int mgs_get_desc(const mgs_handle *h, mgs_desc *out);
 
+/* ---- receive side: record boundaries and container page cuts ---------------
+ * What follows the exchange in the reference: save_data parses the receive
+ * buffer record by record (kv_from_bytes, src/collectiveshuffler.h:563-585,
+ * src/serializer.h:376-403) and KVContainer::write appends each record to the
+ * current page, opening a new page when a record does not fit
+ * (src/kvcontainer.h:133-160).  Pages hold whole records back to back, so a
+ * page is a contiguous slice of the stream; this call finds, on the device,
+ * where the records start and at which records new pages begin, so that the
+ * payload never has to visit the host:
+ *
+ *   d_stream / nbytes   wire-form records back to back (a receive image, or
+ *                       several of them concatenated); nbytes < 4 GiB
+ *   d_rec_off           out, device: d_rec_off[i] = first byte of record i,
+ *                       d_rec_off[n] = nbytes (the same form mgs_pack_device
+ *                       takes as input); rec_off_capacity entries available
+ *   page_bytes          the container's page size (64 MiB in the reference)
+ *   first_page_fill     bytes already in the container's current page
+ *   cuts / n_cuts       out, host: every record at which a NEW page begins;
+ *                       records before cuts[0] continue the current page
+ *
+ * Layouts: fixed-width records; one NUL-terminated key followed by a
+ * fixed-width value of at most 62 bytes, or by no value.  Other layouts
+ * return MGS_ERR_ARG (parse those on the host).  MGS_ERR_MALFORMED: the stream
+ * does not end at a record boundary.  MGS_ERR_RECORD_SIZE: a record is larger
+ * than a page.  Blocking. */
+typedef struct mgs_page_cut {
+    uint64_t first_record; /* index of the first record of the new page */
+    uint64_t first_byte;   /* its offset in the stream */
+} mgs_page_cut;
+
+int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes,
+                      uint32_t *d_rec_off, uint64_t rec_off_capacity,
+                      int64_t page_bytes, int64_t first_page_fill,
+                      uint64_t *n_records, mgs_page_cut *cuts, int max_cuts,
+                      int *n_cuts, void *stream);
+
 /* ---- host-staged front end: what a Writable::write() shim calls -----------
  * The reference serialises every pair into the send buffer inside write()
  * (src/collectiveshuffler.h:143-146) because the caller's pointers die when

@@ -51,6 +51,10 @@ class Desc(C.Structure):
                 ("max_records", C.c_uint64)]
 
 
+class PageCut(C.Structure):
+    _fields_ = [("first_record", C.c_uint64), ("first_byte", C.c_uint64)]
+
+
 class Round(C.Structure):
     _fields_ = [("next", C.c_uint64), ("packed_records", C.c_uint64),
                 ("local_records", C.c_uint64), ("local_bytes", C.c_int64),
@@ -97,6 +101,10 @@ SYMBOLS = {
     "mgs_stager_round_done": (C.c_int, [_VP]),
     "mgs_synth_u64_records": (C.c_int, [_VP, C.c_uint64, C.c_uint64,
                                         C.c_uint64, C.c_int, _VP]),
+    "mgs_unpack_device": (C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64,
+                                    C.c_int64, C.c_int64, C.POINTER(C.c_uint64),
+                                    C.POINTER(PageCut), C.c_int,
+                                    C.POINTER(C.c_int), _VP]),
 }
 
 _lib = None

@@ -19,6 +19,7 @@
 #include "mgs_onesweep16f.h"
 #include "mgs_onesweep16w.h"
 #include "mgs_onesweepv.h"
+#include "mgs_unpack.h"
 
 using namespace mgs;
 
@@ -136,6 +137,8 @@ struct mgs_handle {
     unsigned long long *d_status = nullptr;
     unsigned long long *d_agg16 = nullptr;
     size_t status_bytes = 0, agg16_bytes = 0;
+    uint8_t *d_unp = nullptr;   // receive-side scratch (chunk tables, cuts, result)
+    uint64_t *h_unp = nullptr;  // pinned: result + cuts
     bool pending_osv = false; // the byte-granular one-sweep path was enqueued (may have fallen back)
     int ov_k = 4;             // records per worker lane for variable-width input, adapted call by call
     int pending_ov_k = 4;
@@ -234,6 +237,8 @@ void mgs_destroy(mgs_handle *h)
         if (h->d_dest) (void) hipFree(h->d_dest);
         if (h->d_status) (void) hipFree(h->d_status);
         if (h->d_agg16) (void) hipFree(h->d_agg16);
+        if (h->d_unp) (void) hipFree(h->d_unp);
+        if (h->h_unp) (void) hipHostFree(h->h_unp);
         if (h->h_head) (void) hipHostFree(h->h_head);
         if (h->h_ctrl) (void) hipHostFree(h->h_ctrl);
         if (h->ev0) (void) hipEventDestroy(h->ev0);
@@ -669,6 +674,123 @@ int mgs_get_desc(const mgs_handle *h, mgs_desc *out)
 {
     if (!h || !out) return MGS_ERR_ARG;
     *out = h->desc;
+    return MGS_OK;
+}
+
+// ---- receive side -----------------------------------------------------------------
+constexpr uint32_t kUnpMaxCuts = 4096;
+constexpr size_t kUnpScratch = 8u << 20;
+
+int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint32_t *d_rec_off,
+                      uint64_t rec_off_capacity, int64_t page_bytes, int64_t first_page_fill,
+                      uint64_t *n_records, mgs_page_cut *cuts, int max_cuts, int *n_cuts, void *stream_v)
+{
+    if (!h || !d_rec_off || !n_records || !n_cuts || (nbytes && !d_stream) || (max_cuts > 0 && !cuts)) {
+        if (h) h->err = "mgs_unpack_device: NULL argument";
+        return MGS_ERR_ARG;
+    }
+    const mgs_layout &L = h->desc.layout;
+    if (nbytes >= (1ull << 32) || rec_off_capacity == 0 || page_bytes <= 0 || first_page_fill < 0
+        || first_page_fill > page_bytes || max_cuts < 0) {
+        h->err = "mgs_unpack_device: stream must be under 4 GiB, page_bytes > 0, 0 <= first_page_fill <= page_bytes";
+        return MGS_ERR_ARG;
+    }
+    const bool fixed = h->fixed_len != 0;
+    const bool cstr_fixed = L.key_kind == MGS_KEY_CSTR && L.key_count == 1 && L.val_kind != MGS_VAL_CSTR
+                            && (L.val_kind == MGS_VAL_VOID || L.val_bytes <= UNP_MAX_V);
+    if (!fixed && !cstr_fixed) {
+        h->err = "mgs_unpack_device: layout not supported on the device (one string key + fixed value of "
+                 "at most 62 bytes, or fixed-width records)";
+        return MGS_ERR_ARG;
+    }
+    DeviceGuard g(h->desc.device);
+    if (!g.ok) {
+        h->err = "mgs_unpack_device: hipSetDevice failed";
+        return MGS_ERR_HIP;
+    }
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
+    if (!h->d_unp) MGS_HIP(h, hipMalloc(&h->d_unp, kUnpScratch));
+    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
+
+    UnpParams p;
+    memset(&p, 0, sizeof(p));
+    p.stream = static_cast<const uint8_t *>(d_stream);
+    p.nbytes = nbytes;
+    p.V = (L.val_kind == MGS_VAL_FIXED) ? (uint32_t) L.val_bytes : 0u;
+    const uint32_t S = p.V + 2;
+    // one wave per chunk
+    uint64_t chunk = (nbytes + UNP_MAX_CHUNKS - 1) / UNP_MAX_CHUNKS;
+    chunk = std::max<uint64_t>(4096, (chunk + 1023) / 1024 * 1024);
+    p.chunk_bytes = (uint32_t) chunk;
+    p.nchunks = (uint32_t) ((nbytes + chunk - 1) / chunk);
+    uint8_t *q = h->d_unp;
+    p.result = reinterpret_cast<uint64_t *>(q);               q += 2 * sizeof(uint64_t);
+    p.cuts = reinterpret_cast<uint64_t *>(q);                 q += 2 * kUnpMaxCuts * sizeof(uint64_t);
+    p.first_rec = reinterpret_cast<uint64_t *>(q);            q += ((size_t) p.nchunks + 1) * sizeof(uint64_t);
+    p.count = reinterpret_cast<uint32_t *>(q);                q += (size_t) p.nchunks * S * sizeof(uint32_t);
+    p.entry = reinterpret_cast<uint32_t *>(q);                q += (size_t) p.nchunks * sizeof(uint32_t);
+    p.exit_state = q;                                         q += (size_t) p.nchunks * S;
+    if ((size_t) (q - h->d_unp) > kUnpScratch) {
+        h->err = "mgs_unpack_device: internal scratch too small";
+        return MGS_ERR_ARG;
+    }
+    p.rec_off = d_rec_off;
+    p.rec_cap = rec_off_capacity;
+    p.ctrl = h->d_ctrl;
+    p.page_bytes = page_bytes;
+    p.first_fill = first_page_fill;
+    p.max_cuts = kUnpMaxCuts;
+
+    if (h->pending) { // one call in flight per handle: the control block is shared
+        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    }
+    MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
+    MGS_HIP(h, hipMemsetAsync(p.result, 0, 2 * sizeof(uint64_t), stream));
+    if (nbytes == 0) {
+        MGS_HIP(h, hipMemsetAsync(d_rec_off, 0, sizeof(uint32_t), stream));
+    }
+    else if (fixed) {
+        const uint64_t n = nbytes / h->fixed_len;
+        if (n + 1 > rec_off_capacity) {
+            h->err = "mgs_unpack_device: d_rec_off too small";
+            return MGS_ERR_ARG;
+        }
+        hipLaunchKernelGGL(k_unp_fixed, dim3((unsigned) std::min<uint64_t>(4096, n / 256 + 1)), dim3(256), 0,
+                           stream, p, h->fixed_len);
+    }
+    else {
+        hipLaunchKernelGGL(k_unp_spec, dim3(p.nchunks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_unp_chain, dim3(1), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_unp_emit, dim3(p.nchunks), dim3(64), 0, stream, p);
+    }
+    hipLaunchKernelGGL(k_unp_pages, dim3(1), dim3(64), 0, stream, p);
+    MGS_HIP(h, hipGetLastError());
+    MGS_HIP(h, hipMemcpyAsync(h->h_unp, p.result, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipMemcpyAsync(&h->h_ctrl->head.error, &h->d_ctrl->head.error, sizeof(int32_t),
+                              hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipStreamSynchronize(stream));
+    const int derr = h->h_ctrl->head.error;
+    if (derr != 0) {
+        switch (derr) {
+        case MGS_ERR_MALFORMED: h->err = "the stream does not end at a record boundary"; break;
+        case MGS_ERR_RECORD_SIZE: h->err = fmt("a record is larger than one page (%lld)", (long long) page_bytes); break;
+        case MGS_ERR_ARG: h->err = "mgs_unpack_device: d_rec_off too small"; break;
+        default: h->err = fmt("device error %d", derr);
+        }
+        return derr;
+    }
+    *n_records = h->h_unp[0];
+    const uint64_t nc = h->h_unp[1];
+    if (nc > (uint64_t) max_cuts || nc > kUnpMaxCuts) {
+        h->err = fmt("mgs_unpack_device: %llu page cuts, room for %d", (unsigned long long) nc, max_cuts);
+        return MGS_ERR_ARG;
+    }
+    for (uint64_t k = 0; k < nc; k++) {
+        cuts[k].first_record = h->h_unp[2 + 2 * k];
+        cuts[k].first_byte = h->h_unp[3 + 2 * k];
+    }
+    *n_cuts = (int) nc;
     return MGS_OK;
 }
 

@@ -111,6 +111,10 @@ class DevicePacker:
             init, init_p = None, None
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
+            if not stream:
+                # the library maps the null stream to its own non-blocking stream, which
+                # is not ordered after torch's default stream: finish what produced the inputs
+                torch.cuda.current_stream(self.device).synchronize()
         local_cap = local_out.numel() if local_out is not None else 0
         return (self.h, _ptr(records), _ptr(rec_off), n_end, start, init_p,
                 _ptr(send_image), _ptr(local_out), local_cap, _ptr(dest_out),
@@ -137,6 +141,28 @@ class DevicePacker:
         r = capi.Round()
         self._check(self.lib.mgs_pack_result(self.h, C.byref(r)))
         return RoundResult(r, self.nranks)
+
+
+def unpack_stream(packer, stream, nbytes, page_bytes=64 << 20, first_page_fill=0,
+                  max_cuts=1024, rec_off=None):
+    """Record offsets (device uint32 tensor, n+1 entries) and page cuts of a
+    device-resident wire-form stream: save_data + KVContainer::write without
+    moving the payload.  Returns (rec_off, n_records, [(first_record, first_byte), ...])."""
+    fl = packer.layout.fixed_len()
+    cap = (nbytes // fl if fl else nbytes // 2) + 2
+    if rec_off is None:
+        rec_off = torch.empty(cap, dtype=torch.int32, device=stream.device)
+    n = C.c_uint64()
+    ncuts = C.c_int()
+    cuts = (capi.PageCut * max_cuts)()
+    s = torch.cuda.current_stream(packer.device).cuda_stream
+    if not s:  # see DevicePacker._args
+        torch.cuda.current_stream(packer.device).synchronize()
+    packer._check(packer.lib.mgs_unpack_device(
+        packer.h, _ptr(stream), nbytes, _ptr(rec_off), rec_off.numel(), page_bytes, first_page_fill,
+        C.byref(n), cuts, max_cuts, C.byref(ncuts), C.c_void_p(s)))
+    return rec_off, int(n.value), [(int(cuts[i].first_record), int(cuts[i].first_byte))
+                                   for i in range(ncuts.value)]
 
 
 def synth_u64_records(n, seed=42, first=0, device=0, out=None):

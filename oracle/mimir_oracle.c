@@ -266,3 +266,22 @@ int64_t mo_parse_records(const mo_layout *lay, const uint8_t *buf,
     rec_off_out[nrec] = (uint64_t) pos;
     return nrec;
 }
+
+int64_t mo_page_cuts(const uint64_t *rec_off, int64_t n, int64_t page_bytes,
+                     int64_t first_fill, uint64_t *cut_record_out,
+                     int64_t max_cuts)
+{
+    int64_t fill = first_fill, ncuts = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t len = (int64_t) (rec_off[i + 1] - rec_off[i]);
+        /* kv_to_bytes(ptr, pagesize - datasize) == -1, src/kvcontainer.h:140-142 */
+        if (len > page_bytes - fill) {
+            if (ncuts >= max_cuts) return -1;
+            cut_record_out[ncuts++] = (uint64_t) i; /* add_page(), :143 */
+            fill = 0;
+            if (len > page_bytes) return -1; /* :147-149 */
+        }
+        fill += len;
+    }
+    return ncuts;
+}

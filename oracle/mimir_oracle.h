@@ -117,6 +117,18 @@ int64_t mo_parse_records(const mo_layout *lay, const uint8_t *buf,
                          int64_t nbytes, uint64_t *rec_off_out,
                          int64_t max_records);
 
+/* KVContainer::write (src/kvcontainer.h:133-160) over a parsed stream: every
+ * record is appended to the current page; when it does not fit in what is left
+ * of the page (an exact fit does fit, src/serializer.h:348-364) a new page is
+ * opened and the record goes there.  rec_off[0..n] are the record offsets,
+ * first_fill the bytes already in the current page.  Writes the index of the
+ * first record of every new page to cut_record_out (room for max_cuts) and
+ * returns their number, or -1 when a record is larger than a page (:147-149)
+ * or max_cuts is too small. */
+int64_t mo_page_cuts(const uint64_t *rec_off, int64_t n, int64_t page_bytes,
+                     int64_t first_fill, uint64_t *cut_record_out,
+                     int64_t max_cuts);
+
 #ifdef __cplusplus
 }
 #endif

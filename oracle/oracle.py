@@ -83,7 +83,21 @@ class Oracle:
         L.mo_parse_records.restype = C.c_int64
         L.mo_parse_records.argtypes = [C.POINTER(Layout), C.c_void_p,
                                        C.c_int64, C.c_void_p, C.c_int64]
+        L.mo_page_cuts.restype = C.c_int64
+        L.mo_page_cuts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                   C.c_void_p, C.c_int64]
         self.L = L
+
+    def page_cuts(self, rec_off, page_bytes, first_fill=0):
+        """Indices of the records that open a new container page."""
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        n = len(rec_off) - 1
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        k = self.L.mo_page_cuts(rec_off.ctypes.data, n, page_bytes, first_fill,
+                                out.ctypes.data, len(out))
+        if k < 0:
+            raise ValueError("oracle: record larger than a page")
+        return out[:k]
 
     def hashlittle(self, data: bytes, initval=0):
         buf = C.create_string_buffer(bytes(data), len(data))
