@@ -38,7 +38,7 @@
 namespace mgs {
 
 constexpr int UNP_MAX_V = 62;        // value bytes handled: V + 2 entry states, one lane each
-constexpr int UNP_MAX_CHUNKS = 8192; // one wave each: eight per SIMD on a full device
+constexpr int UNP_MAX_CHUNKS = 4096; // one wave each: four per SIMD on a full device
 
 struct UnpParams {
     const uint8_t *stream;
@@ -223,15 +223,19 @@ __global__ __launch_bounds__(64) void k_unp_chain(UnpParams p)
     constexpr int BATCH = 16;
     uint32_t state = 0; // the stream starts at a record boundary
     uint64_t total = 0;
-    for (uint32_t c0 = 0; c0 < p.nchunks; c0 += BATCH) {
-        uint32_t ex[BATCH], cn[BATCH];
+    const uint32_t x = min((uint32_t) lane, S - 1);
+    auto fetch = [&](uint32_t c0, uint32_t (&ex)[BATCH], uint32_t (&cn)[BATCH]) {
 #pragma unroll
         for (int j = 0; j < BATCH; j++) {
             const uint32_t c = min(c0 + j, p.nchunks - 1);
-            const uint32_t x = min((uint32_t) lane, S - 1);
             ex[j] = p.exit_state[(uint64_t) c * S + x];
             cn[j] = p.count[(uint64_t) c * S + x];
         }
+    };
+    uint32_t ex[BATCH], cn[BATCH], ex2[BATCH], cn2[BATCH];
+    fetch(0, ex, cn);
+    for (uint32_t c0 = 0; c0 < p.nchunks; c0 += BATCH) {
+        if (c0 + BATCH < p.nchunks) fetch(c0 + BATCH, ex2, cn2); // in flight during this batch
         uint32_t my_entry = 0;
         uint64_t my_first = 0;
 #pragma unroll
@@ -248,6 +252,11 @@ __global__ __launch_bounds__(64) void k_unp_chain(UnpParams p)
         if (lane < BATCH && c0 + lane < p.nchunks) {
             p.entry[c0 + lane] = my_entry;
             p.first_rec[c0 + lane] = my_first;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            ex[j] = ex2[j];
+            cn[j] = cn2[j];
         }
     }
     if (lane == 0) {
