@@ -17,10 +17,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmimir_gpu_shuffle.so")
 SOURCES = [os.path.join(CSRC, "mgs_api.hip"), os.path.join(CSRC, "mgs_stager.hip")]
-HEADERS = [os.path.join(CSRC, f) for f in
-           ("mgs_common.h", "mgs_generic.h", "mgs_onesweep16.h", "mgs_onesweep16s.h",
-            "mgs_onesweep16d.h", "mgs_onesweep16e.h", "mgs_onesweep16p.h", "mgs_onesweep16f.h")] + [
-               os.path.join(ROOT, "include", "mimir_gpu_shuffle.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+    os.path.join(ROOT, "include", "mimir_gpu_shuffle.h")]
 ARCH = "gfx950"
 
 

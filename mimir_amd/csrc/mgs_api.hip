@@ -13,8 +13,6 @@
 #include "mgs_generic.h"
 #include "mgs_onesweep16.h"
 #include "mgs_onesweep16s.h"
-#include "mgs_onesweep16d.h"
-#include "mgs_onesweep16e.h"
 #include "mgs_onesweep16p.h"
 #include "mgs_onesweep16f.h"
 #include "mgs_onesweep16w.h"
@@ -74,9 +72,6 @@ struct OsVariant {
 #define OSV(name, T, I, V, B) {name, T, I, B, T * I, false, SAME7((k_onesweep16<T, I, V, MINW_(T, B)>))}
 #define OSS(name, T, I, V, B) \
     {name, T, I, B, (T / 64 - 1) * 64 * I, false, SAME7((k_onesweep16s<T, I, V, MINW_(T, B)>))}
-#define OSD(name, T, I, V, B) {name, T, I, B, T * I, false, SAME7((k_onesweep16d<T, I, V, MINW_(T, B)>))}
-#define OSE(name, T, I, V, B) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, false, SAME7((k_onesweep16e<T, I, V, MINW_(T, B)>))}
 #define OSP(name, T, I, V, B, L) \
     {name, T, I, B, (T / 64 - 1) * 64 * I, false, SAME7((k_onesweep16p<T, I, V, MINW_(T, B), L>))}
 #define OSF(name, T, I, V, B, L) \
@@ -104,14 +99,10 @@ static const OsVariant kOsVariants[] = {
     OSP("p512x8-w16", 512, 8, 0, 2, 16),                    // 14: scan wave, split loops, 128-tile walk
     OSP("p512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 16),
     OSP("p512x8-w16-stats", 512, 8, OSV_STATS, 2, 16),      // 16
-    OSD("d512x8", 512, 8, 0, 2),                            // direct scatter from registers
-    OSD("d512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),     // 18
-    OSE("e512x8", 512, 8, 0, 2),                            // direct scatter, two register sets
-    OSE("e512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),     // 20
-    OSF("f512x8-w16-d3", 512, 8, 3 << OSV_DELAY_SHIFT, 2, 16), // direct scatter, tile parked in LDS
-    OSF("f512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8),  // 22
-    OSF("f512x8-w16-stats", 512, 8, OSV_STATS, 2, 16),
-    OSF("g512x8-w12-d3", 512, 8, OSV_WINDOW | (3 << OSV_DELAY_SHIFT), 2, 12), // 24: f with the windowed scan
+    OSF("f512x8-w16-d3", 512, 8, 3 << OSV_DELAY_SHIFT, 2, 16), // 17: direct scatter, tile parked in LDS
+    OSF("f512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8),
+    OSF("f512x8-w16-stats", 512, 8, OSV_STATS, 2, 16),      // 19
+    OSF("g512x8-w12-d3", 512, 8, OSV_WINDOW | (3 << OSV_DELAY_SHIFT), 2, 12), // f with the windowed scan
     OSF("g512x8-w12-d3-stats", 512, 8, OSV_WINDOW | OSV_STATS | (3 << OSV_DELAY_SHIFT), 2, 12),
 };
 constexpr int kNumOsVariants = (int) (sizeof(kOsVariants) / sizeof(kOsVariants[0]));
