@@ -105,8 +105,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--records", type=float, default=1e9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algo", default="auto", choices=["auto", "generic", "onesweep16"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "generic", "onesweep16", "onesweepv"])
+    ap.add_argument("--workload", default="u64", choices=["u64", "words", "join", "octree"],
+                    help="u64: the headline configuration; words / join / octree: the other record "
+                         "shapes (host-generated, default 5e7 records per GPU)")
+    ap.add_argument("--level", type=int, default=12, help="octree: key characters per record")
     args = ap.parse_args()
+    if args.workload != "u64" and args.records == 1e9:
+        args.records = 5e7
 
     import torch
     import torch.distributed as dist
@@ -127,11 +133,37 @@ def main():
     P = 8 if not distributed else world
     self_rank = -1 if not distributed else rank
     algo = {"auto": capi.ALGO_AUTO, "generic": capi.ALGO_GENERIC,
-            "onesweep16": capi.ALGO_ONESWEEP16}[args.algo]
-    lay = capi.Layout.make(capi.KEY_FIXED, 8, capi.VAL_FIXED, 8)
-    # one round holds the whole batch: capacity = expected share + 1/64 slack
-    buf_size = 16 * (n // P + n // 64 + 4096)
-    records = synth_u64_records(n, seed=42 + rank, first=rank * n, device=dev)
+            "onesweep16": capi.ALGO_ONESWEEP16, "onesweepv": capi.ALGO_ONESWEEPV}[args.algo]
+    rec_off = None
+    if args.workload == "u64":
+        lay = capi.Layout.make(capi.KEY_FIXED, 8, capi.VAL_FIXED, 8)
+        # one round holds the whole batch: capacity = expected share + 1/64 slack
+        buf_size = 16 * (n // P + n // 64 + 4096)
+        records = synth_u64_records(n, seed=42 + rank, first=rank * n, device=dev)
+        total_bytes, algo_bytes = 16 * n, n * ALGO_BYTES_PER_RECORD
+        what, data = "configs[1]: fixed-width <uint64,uint64> records", \
+            "synthetic (seeded splitmix64 keys, value = record index)"
+    else:
+        import numpy as np
+        from mimir_amd import datagen
+        if args.workload == "words":   # gen_words-like corpus: Zipf over a vocabulary, word\0 + u64 count
+            blob, offs, lt = datagen.word_records(n, 1_000_000, 1.0, 6, 1.0, seed=44 + rank)
+            what = "configs[3]: wordcount records (NUL-terminated word + uint64), Zipf(1.0) over 1e6 words"
+        elif args.workload == "join":  # gen_tables-like: word\0 + {tag, pad, int64}
+            blob, offs, lt = datagen.join_records(n, seed=45 + rank)
+            what = "configs[4]: join records (NUL-terminated key + 16-byte tagged value), Zipf keys"
+        else:                          # octree level pass: `level` key characters + u64 count
+            blob, offs, lt = datagen.octree_records(n, level=args.level, seed=43 + rank)
+            what = f"configs[2]: octree level-{args.level} records ({args.level}-char octant key + uint64)"
+        lay = capi.Layout.make(*lt)
+        total_bytes = int(blob.shape[0])
+        records = torch.from_numpy(blob).to(f"cuda:{dev}")
+        if offs is not None:
+            rec_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).to(f"cuda:{dev}")
+        # skewed keys: leave room for four times the even share
+        buf_size = (min(total_bytes, 4 * total_bytes // P) + 65536) // 16 * 16
+        algo_bytes = 2 * total_bytes + (4 * (n + 1) if offs is not None else 0)
+        data = "synthetic (seeded host generator, mimir_amd/datagen.py)"
     pk = DevicePacker(lay, P, self_rank, buf_size, max_records=n, device=dev)
     image = pk.new_send_image()
     local = torch.empty(buf_size, dtype=torch.uint8, device=f"cuda:{dev}") if distributed else None
@@ -144,7 +176,7 @@ def main():
     def step():
         nonlocal sent_max
         t0 = time.perf_counter()
-        r = pk.pack(records, n, image, local_out=local, algo=algo)
+        r = pk.pack(records, n, image, rec_off=rec_off, local_out=local, algo=algo)
         pack_s.append(time.perf_counter() - t0)
         if r.next != n:
             raise RuntimeError(f"round cut at {r.next}: partition capacity too small")
@@ -177,11 +209,11 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n * world * args.steps / dt
     k_ms = sum(kernel_ms) / len(kernel_ms)
-    achieved = n * ALGO_BYTES_PER_RECORD / (k_ms * 1e-3) / 1e9
-    kname = pk.tuning_name() if pk.last_algo() == "onesweep16" else "generic"
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+    kname = pk.tuning_name() if pk.last_algo() == "onesweep16" else pk.last_algo()
     # variant names start with the kernel family's letter (t = the plain kernel)
     kernel = {"onesweep16": "k_onesweep16" + ("<" if kname.startswith("t") else kname[:1]),
-              "generic": "k_gen_scatter"}[pk.last_algo()]
+              "onesweepv": "k_onesweepv", "generic": "k_gen_scatter"}[pk.last_algo()]
     out = {
         "metric": "device-resident KV records/s hash-partitioned & packed",
         "value": value,
@@ -194,20 +226,20 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32",
-        "data": "synthetic (seeded splitmix64 keys, value = record index)",
-        "GBps_algorithmic": value * ALGO_BYTES_PER_RECORD / 1e9,
+        "data": data,
+        "GBps_algorithmic": value * algo_bytes / n / 1e9,
         "config": {
-            "workload": ("configs[1]: fixed-width <uint64,uint64> records, hash-partition+pack into "
-                         f"{P} destination partitions" + (", then RCCL all-to-all" if distributed else "")),
-            "records_per_gpu": n, "record_bytes": 16, "partitions": P,
+            "workload": (what + f", hash-partition+pack into {P} destination partitions"
+                         + (", then RCCL all-to-all" if distributed else "")),
+            "records_per_gpu": n, "record_bytes": total_bytes / n, "partitions": P,
             "local_bypass": distributed, "kernel_variant": kname,
-            "rounds": "one round holds the batch (buf_size = share + 1/64 slack)",
+            "rounds": "one round holds the batch",
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": committed_traffic(kernel, n) if not distributed else None,
                      "kernel": kernel, "kernel_ms": k_ms,
-                     "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_RECORD},
+                     "algorithmic_bytes_per_launch": algo_bytes},
     }
     if distributed:
         pack_only = n * world / (sum(pack_s) / len(pack_s))
@@ -216,7 +248,7 @@ def main():
         out["exchange"] = {"hottest_pair_bytes": sent_max, "exchange_ms": xfer_s * 1e3,
                            "xgmi_floor_ms": sent_max / (XGMI_LINK_GBS * 1e9) * 1e3,
                            "frac_of_xgmi_pair_roofline": (sent_max / (XGMI_LINK_GBS * 1e9)) / max(xfer_s, 1e-9)}
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
+    if rank == 0 and not distributed and not args.no_cpu_baseline and args.workload == "u64":
         del image
         torch.cuda.empty_cache()
         single = cpu_baseline(records, n)
