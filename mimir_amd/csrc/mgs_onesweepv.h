@@ -7,28 +7,34 @@
 // counted in bytes.
 //
 //   stage     the tile's span is loaded with aligned 16-byte loads (whole-wave
-//             contiguous accesses) and parked in LDS (`sin`);
+//             contiguous accesses) and parked in LDS (`sin`); the offsets of
+//             the tile after next and the bytes of the next tile are in flight
+//             while this one is processed;
 //   hash      lane l owns K consecutive records: key length by the layout's
 //             rule (src/serializer.h:418-421), lookup3 over the key bytes read
-//             from LDS as unaligned dwords, dest = hash % nranks;
-//   rank      emit order inside a tile is (wave, lane, k).  For every
-//             destination b one wave scan over the lanes' byte totals for b
-//             gives each lane its start inside the wave's share of b; inside a
-//             lane the K records are accumulated in order.  Wave totals per
-//             destination go to LDS; the last worker wave to finish publishes
-//             the tile's per-destination byte counts (16-bit fields) for the
-//             chained scan, before the barrier;
+//             from LDS, dest = hash % nranks;
+//   rank      emit order inside a tile is (wave, lane, k).  Per pair of
+//             destinations one wave scan (two 16-bit fields) over the lanes'
+//             byte totals gives each lane its start inside the wave's share;
+//             inside a lane the K records are accumulated in order.  Wave
+//             totals per destination go to LDS; the last worker wave to finish
+//             publishes the tile's per-destination byte counts (16-bit fields)
+//             for the chained scan, before the barrier;
 //   reorder   records are copied LDS -> LDS into an image grouped by
-//             destination (`sout`), byte-granular, stable;
+//             destination (`sout`), byte-granular, stable: the first 16 bytes of
+//             every record by two aligned reads and a funnel shift, written as
+//             pieces of 8/4/2/1 bytes;
 //   chain     the windowed chained scan of mgs_onesweep16w.h, run by a scan
 //             wave, over byte counts; its first poll is in flight across the
 //             workers' two staging barriers;
 //   store     one trip later, the image is streamed out in 16-byte chunks
-//             aligned to the *global* address of each partition run (unaligned
-//             LDS reads, aligned full-line-friendly global stores); the partial
-//             chunks at the two ends of a run are written byte by byte.  A run
-//             is clipped at the partition's capacity; a clipped tile records its
-//             index (round cut), k_osv_finalize re-walks that one tile.
+//             aligned to the *global* address of each partition run (aligned
+//             LDS reads + funnel shift, aligned global stores); a wave takes 64
+//             consecutive chunks of one destination at a time; the partial
+//             chunks at the two ends of a run go out as naturally aligned
+//             pieces.  A run is clipped at the partition's capacity; a clipped
+//             tile records its index (round cut), k_osv_finalize re-walks that
+//             one tile.
 //
 // The kernel needs every tile's span to fit the LDS staging buffer.  For
 // variable-width input k_osv_check tests that on the device first and raises
