@@ -251,7 +251,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
             if (lane == 0) arrive[par ^ 1] = 0;
             __syncthreads(); // B
             const uint32_t next2 = misc[1];
-            if (tile != 0) {
+            if ((VAR & OSV_FAKE_CHAIN) && tile != 0) { // timing only: made-up positions, no scan
+                ov_raw_barrier(); // C
+                ov_raw_barrier(); // D
+                acc = (unsigned long long) tile * 3600ull;
+            }
+            else if (tile != 0) {
                 // first poll in flight across the workers' two staging barriers
                 acc = os_window_walk<VAR, LOOK>(p, tile, lane, &ws, [] {
                     ov_raw_barrier(); // C

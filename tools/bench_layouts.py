@@ -55,7 +55,7 @@ def main():
             ev1.record(stream)
             res = pk.result()
             torch.cuda.synchronize()
-            assert res.next == n, (name, res)
+            assert res.next == n or os.environ.get("MGS_OSV_STATS") == "2", (name, res)
             if r:
                 ms.append(ev0.elapsed_time(ev1))
         ms.sort()
