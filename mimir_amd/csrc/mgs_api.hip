@@ -128,7 +128,8 @@ struct mgs_handle {
     unsigned long long *d_status = nullptr;
     unsigned long long *d_agg16 = nullptr;
     size_t status_bytes = 0, agg16_bytes = 0;
-    uint8_t *d_unp = nullptr;   // receive-side scratch (chunk tables, cuts, result)
+    uint8_t *d_unp = nullptr;   // receive-side scratch (chunk and piece tables, cuts, result)
+    size_t unp_bytes = 0;
     uint64_t *h_unp = nullptr;  // pinned: result + cuts
     bool pending_osv = false; // the byte-granular one-sweep path was enqueued (may have fallen back)
     int ov_k = 4;             // records per worker lane for variable-width input, adapted call by call
@@ -672,7 +673,7 @@ int mgs_get_desc(const mgs_handle *h, mgs_desc *out)
 
 // ---- receive side -----------------------------------------------------------------
 constexpr uint32_t kUnpMaxCuts = 4096;
-constexpr size_t kUnpScratch = 8u << 20;
+constexpr size_t kUnpScratch = 8u << 20; // first allocation; grows with the stream
 
 int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint32_t *d_rec_off,
                       uint64_t rec_off_capacity, int64_t page_bytes, int64_t first_page_fill,
@@ -702,7 +703,6 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
         return MGS_ERR_HIP;
     }
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
-    if (!h->d_unp) MGS_HIP(h, hipMalloc(&h->d_unp, kUnpScratch));
     if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
 
     UnpParams p;
@@ -711,22 +711,41 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     p.nbytes = nbytes;
     p.V = (L.val_kind == MGS_VAL_FIXED) ? (uint32_t) L.val_bytes : 0u;
     const uint32_t S = p.V + 2;
-    // one wave per chunk
+    // one wave per chunk, one lane per piece; pieces of at least four 64-byte blocks
     uint64_t chunk = (nbytes + UNP_MAX_CHUNKS - 1) / UNP_MAX_CHUNKS;
-    chunk = std::max<uint64_t>(4096, (chunk + 1023) / 1024 * 1024);
+    chunk = std::max<uint64_t>(16384, (chunk + 4095) / 4096 * 4096);
     p.chunk_bytes = (uint32_t) chunk;
+    p.piece_bytes = (uint32_t) (chunk / UNP_PIECES);
     p.nchunks = (uint32_t) ((nbytes + chunk - 1) / chunk);
-    uint8_t *q = h->d_unp;
-    p.result = reinterpret_cast<uint64_t *>(q);               q += 2 * sizeof(uint64_t);
-    p.cuts = reinterpret_cast<uint64_t *>(q);                 q += 2 * kUnpMaxCuts * sizeof(uint64_t);
-    p.first_rec = reinterpret_cast<uint64_t *>(q);            q += ((size_t) p.nchunks + 1) * sizeof(uint64_t);
-    p.count = reinterpret_cast<uint32_t *>(q);                q += (size_t) p.nchunks * S * sizeof(uint32_t);
-    p.entry = reinterpret_cast<uint32_t *>(q);                q += (size_t) p.nchunks * sizeof(uint32_t);
-    p.exit_state = q;                                         q += (size_t) p.nchunks * S;
-    if ((size_t) (q - h->d_unp) > kUnpScratch) {
-        h->err = "mgs_unpack_device: internal scratch too small";
-        return MGS_ERR_ARG;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t tables = (size_t) p.nchunks * UNP_PIECES * S;
+    const size_t need = up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t))
+                        + up(((size_t) p.nchunks + 1) * sizeof(uint64_t)) + up((size_t) p.nchunks * S * sizeof(uint32_t))
+                        + up((size_t) p.nchunks * sizeof(uint32_t)) + up((size_t) p.nchunks * S)
+                        + up(tables * sizeof(uint16_t)) + up(tables);
+    if (h->pending) { // one call in flight per handle: the control block and the scratch are shared
+        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
     }
+    if (need > h->unp_bytes) {
+        if (h->d_unp) {
+            MGS_HIP(h, hipDeviceSynchronize());
+            MGS_HIP(h, hipFree(h->d_unp));
+            h->d_unp = nullptr;
+            h->unp_bytes = 0;
+        }
+        const size_t want = std::max(need, kUnpScratch);
+        MGS_HIP(h, hipMalloc(&h->d_unp, want));
+        h->unp_bytes = want;
+    }
+    uint8_t *q = h->d_unp;
+    p.result = reinterpret_cast<uint64_t *>(q); // result and cuts leave with one copy
+    p.cuts = p.result + 2;                                    q += up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t));
+    p.first_rec = reinterpret_cast<uint64_t *>(q);            q += up(((size_t) p.nchunks + 1) * sizeof(uint64_t));
+    p.count = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * S * sizeof(uint32_t));
+    p.entry = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * sizeof(uint32_t));
+    p.exit_state = q;                                         q += up((size_t) p.nchunks * S);
+    p.piece_count = reinterpret_cast<uint16_t *>(q);          q += up(tables * sizeof(uint16_t));
+    p.piece_exit = q;                                         q += up(tables);
     p.rec_off = d_rec_off;
     p.rec_cap = rec_off_capacity;
     p.ctrl = h->d_ctrl;
@@ -734,9 +753,6 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     p.first_fill = first_page_fill;
     p.max_cuts = kUnpMaxCuts;
 
-    if (h->pending) { // one call in flight per handle: the control block is shared
-        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
-    }
     MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
     MGS_HIP(h, hipMemsetAsync(p.result, 0, 2 * sizeof(uint64_t), stream));
     if (nbytes == 0) {
@@ -752,9 +768,11 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
                            stream, p, h->fixed_len);
     }
     else {
-        hipLaunchKernelGGL(k_unp_spec, dim3(p.nchunks), dim3(64), 0, stream, p);
+        const size_t lds_spec = (2 * (size_t) S * 65 + 128) * sizeof(uint32_t);
+        const size_t lds_emit = ((((size_t) UNP_PIECES * S + 128 + 3) & ~(size_t) 3) + 64 * UNP_SLOT_PITCH) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_unp_spec, dim3(p.nchunks), dim3(64), lds_spec, stream, p);
         hipLaunchKernelGGL(k_unp_chain, dim3(1), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_unp_emit, dim3(p.nchunks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_unp_emit, dim3(p.nchunks), dim3(64), lds_emit, stream, p);
     }
     hipLaunchKernelGGL(k_unp_pages, dim3(1), dim3(64), 0, stream, p);
     MGS_HIP(h, hipGetLastError());

@@ -12,24 +12,29 @@
 //
 // Records of a string key followed by a V-byte value cannot be found by
 // looking for NULs alone (value bytes may be zero), the parse is a chain:
-// after a key's NUL skip V bytes, the next key starts there.  The chain is
-// broken into chunks, one wave each:
+// after a key's NUL skip V bytes, the next key starts there.  The chain is cut
+// twice: the stream into chunks, one wave each, and a chunk into 64 pieces, one
+// lane each, so that the walk over the NUL bits is vector work (as wave-uniform
+// scalar work it is bound by the one scalar unit of a compute unit).
 //
-//   k_unp_spec   the chunk is parsed for every state it could be entered in
-//                (x = 0..V bytes still to skip, or the middle of a key); lane x
-//                keeps state x.  Per 64-byte block the wave makes a 64-bit NUL
-//                mask (one byte per lane, ballot) and steps the states one
-//                after the other as wave-uniform scalar work -- states that
-//                have met (after a few records they all have) are stepped
-//                once, so the cost is that of one parse.  (Letting every lane
-//                walk its own bits in a divergent loop gave wrong counts now
-//                and then on gfx950; the uniform form does not.)
-//                Out: exit state and record count per entry state.
+//   k_unp_spec   a lane parses its piece for every state it could be entered in
+//                (x = 0..V bytes still to skip, or the middle of a key).  Entry
+//                states that have led to the same state are stepped once, and
+//                once all have met (after a record or two they have) the lane
+//                goes on with one parse.  The 64 piece tables (entry state ->
+//                exit state, records) are kept for k_unp_emit and composed into
+//                the chunk's table.
 //   k_unp_chain  one wave follows the chain through the chunks -> entry state
 //                and first record index of every chunk.
-//   k_unp_emit   every wave parses its chunk again, now from its true entry
-//                state, and writes the record start offsets.
+//   k_unp_emit   the chunk's entry state is walked through the piece tables,
+//                then every lane parses its piece again from its true entry
+//                state and writes the record start offsets.
 //   k_unp_pages  one thread: greedy page cuts by binary search in the offsets.
+//
+// Reading: per 64-byte step the wave fetches 64 rows (the lanes' current blocks)
+// as 16 rows x 64 contiguous bytes per load instruction, turns every 16 bytes
+// into a 16-bit NUL mask where they land, and hands the masks to their rows'
+// lanes through LDS (2 bytes per 16 instead of the bytes themselves).
 #ifndef MGS_UNPACK_H
 #define MGS_UNPACK_H
 
@@ -37,17 +42,21 @@
 
 namespace mgs {
 
-constexpr int UNP_MAX_V = 62;        // value bytes handled: V + 2 entry states, one lane each
+constexpr int UNP_MAX_V = 62;        // value bytes handled: V + 2 entry states
 constexpr int UNP_MAX_CHUNKS = 4096; // one wave each: four per SIMD on a full device
+constexpr int UNP_PIECES = 64;       // pieces of a chunk, one lane each
 
 struct UnpParams {
     const uint8_t *stream;
     uint64_t nbytes;
     uint32_t V;           // bytes to skip after a key's NUL
-    uint32_t chunk_bytes; // multiple of 1024
+    uint32_t chunk_bytes; // 64 pieces
+    uint32_t piece_bytes; // multiple of 64, below 65536 (record counts of a piece are 16-bit)
     uint32_t nchunks;
-    uint8_t *exit_state;  // [nchunks][V+1]
-    uint32_t *count;      // [nchunks][V+1]
+    uint8_t *exit_state;  // [nchunks][V+2]
+    uint32_t *count;      // [nchunks][V+2]
+    uint8_t *piece_exit;  // [nchunks][64][V+2]
+    uint16_t *piece_count; // [nchunks][64][V+2]
     uint32_t *entry;      // [nchunks] entry state of each chunk
     uint64_t *first_rec;  // [nchunks+1] index of the chunk's first record start (+ total)
     uint32_t *rec_off;    // out: rec_off[i] = start of record i; rec_off[n] = nbytes
@@ -93,27 +102,46 @@ __device__ __forceinline__ uint32_t unp_m16(const UnpParams &p, uint64_t at, con
     return m;
 }
 
-// The NUL mask of 64-byte block b (0..15) of the kilobyte whose 16-byte pieces the
-// lanes hold in m16: lanes 4b..4b+3.
-template <int B>
-__device__ __forceinline__ uint64_t unp_block_mask(uint32_t m16)
+// Block b of all 64 pieces of the chunk at c0: load j (0..3) of a lane covers 16
+// bytes of row 16j + lane/4, so one load instruction reads 16 rows x 64 bytes.
+struct UnpRows {
+    uint4 raw[4];
+};
+
+__device__ __forceinline__ uint64_t unp_row_at(const UnpParams &p, uint64_t c0, uint32_t b, int j, int lane)
 {
-    const uint32_t a = (uint32_t) __builtin_amdgcn_readlane((int) m16, 4 * B);
-    const uint32_t b = (uint32_t) __builtin_amdgcn_readlane((int) m16, 4 * B + 1);
-    const uint32_t c = (uint32_t) __builtin_amdgcn_readlane((int) m16, 4 * B + 2);
-    const uint32_t d = (uint32_t) __builtin_amdgcn_readlane((int) m16, 4 * B + 3);
-    return (uint64_t) (a | (b << 16)) | ((uint64_t) (c | (d << 16)) << 32);
+    return c0 + (uint64_t) (16 * j + (lane >> 2)) * p.piece_bytes + 64u * b + 16u * (uint32_t) (lane & 3);
+}
+
+__device__ __forceinline__ void unp_rows_load(const UnpParams &p, uint64_t c0, uint32_t b, int lane, UnpRows &r)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) r.raw[j] = unp_load16(p, unp_row_at(p, c0, b, j, lane));
+}
+
+// The masks of the rows just loaded go to LDS (256 x 16 bit); the lane's own
+// 64-bit mask comes back.
+__device__ __forceinline__ uint64_t unp_rows_mask(const UnpParams &p, uint64_t c0, uint32_t b, int lane,
+                                                  const UnpRows &r, uint16_t *smask)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) smask[64 * j + lane] = (uint16_t) unp_m16(p, unp_row_at(p, c0, b, j, lane), r.raw[j]);
+    __syncthreads();
+    const uint64_t nul = reinterpret_cast<const uint64_t *>(smask)[lane];
+    __syncthreads();
+    return nul;
 }
 
 // One 64-byte block for one state.  state: bytes to skip before the next key
 // starts (0..V), or UNP_INKEY when the block is entered in the middle of a key.
-// A record start is noted (bit in `starts`, n++) wherever a key begins inside
-// the `valid` stream bytes of the block.  Returns the state at the block's end
-// (for a partial last block: the bytes still owed, 0 = clean end).
+// put(pos) is called wherever a key begins inside the `valid` stream bytes of
+// the block.  Returns
+// the state at the block's end (for a partial last block: the bytes still
+// owed, 0 = clean end; for valid = 0 the state itself).
 constexpr uint32_t UNP_INKEY = 0x80000000u;
 
-__device__ __forceinline__ uint32_t unp_step(uint64_t nul, uint32_t state, uint32_t V, uint32_t valid,
-                                             uint64_t &starts, uint32_t &n)
+template <class Put>
+__device__ __forceinline__ uint32_t unp_step(uint64_t nul, uint32_t state, uint32_t V, uint32_t valid, Put &&put)
 {
     uint32_t pos;
     if (state & UNP_INKEY) {
@@ -124,8 +152,7 @@ __device__ __forceinline__ uint32_t unp_step(uint64_t nul, uint32_t state, uint3
         pos = state;
     }
     while (pos < valid) {
-        starts |= 1ull << pos; // a key begins here
-        n++;
+        put(pos); // a key begins here
         const uint64_t mm = nul & (~0ull << pos);
         if (mm == 0) return UNP_INKEY; // the key runs on into the next block
         pos = (uint32_t) __ffsll((unsigned long long) mm) + V;
@@ -133,82 +160,77 @@ __device__ __forceinline__ uint32_t unp_step(uint64_t nul, uint32_t state, uint3
     return pos - valid;
 }
 
-// States: 0..V = bytes to skip; "inside a key" is one more state.  Lane x keeps
-// entry state x (x <= V), lane V+1 "inside a key".  A wave reads its chunk a
-// kilobyte at a time (16 bytes per lane, the next kilobyte in flight while this
-// one is parsed).
-template <int B>
-__device__ __forceinline__ void unp_spec_block(const UnpParams &p, uint32_t m16, uint64_t off, uint64_t c1,
-                                               int lane, uint32_t S, uint32_t &state, uint32_t &n, bool &merged)
-{
-    const uint64_t boff = off + 64u * B;
-    if (boff >= c1) return;
-    const uint64_t nul = unp_block_mask<B>(m16);
-    const uint32_t valid = (uint32_t) min((uint64_t) 64, c1 - boff);
-    if (merged) { // every entry state has led to the same state: one parse serves all
-        const uint32_t st = (uint32_t) __builtin_amdgcn_readfirstlane((int) state);
-        uint64_t starts = 0;
-        uint32_t dn = 0;
-        state = unp_step(nul, st, p.V, valid, starts, dn);
-        n += dn;
-        return;
-    }
-    // every state in turn, as wave-uniform scalar work
-    uint32_t prev_in = 0xFFFFFFFFu, prev_out = 0, prev_n = 0;
-    for (uint32_t x = 0; x < S; x++) {
-        const uint32_t st = (uint32_t) __builtin_amdgcn_readlane((int) state, (int) x);
-        if (st != prev_in) {
-            uint64_t starts = 0;
-            prev_n = 0;
-            prev_out = unp_step(nul, st, p.V, valid, starts, prev_n);
-            prev_in = st;
-        }
-        if ((uint32_t) lane == x) {
-            state = prev_out;
-            n += prev_n;
-        }
-    }
-    const uint32_t s0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) state);
-    merged = __ballot((uint32_t) lane < S && state != s0) == 0;
-}
-
+// States as table indices: 0..V = bytes to skip, V+1 = inside a key.
+// Dynamic LDS: states [S][65], counts [S][65] (a lane's column; the pitch of 65
+// keeps the composition's reads apart), then the 256 block masks.
 __global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
 {
+    extern __shared__ uint32_t unp_lds[];
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = blockIdx.x, V = p.V, S = V + 2;
+    uint32_t *sst = unp_lds, *scn = unp_lds + S * 65;
+    uint16_t *smask = reinterpret_cast<uint16_t *>(unp_lds + 2 * S * 65);
     const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
-    const uint64_t c1 = min(p.nbytes, c0 + p.chunk_bytes);
-    const uint32_t S = p.V + 2; // number of states
-    uint32_t state = ((uint32_t) lane == p.V + 1) ? UNP_INKEY : (uint32_t) lane;
-    uint32_t n = 0;
-    bool merged = false;
-    uint4 raw = unp_load16(p, c0 + 16u * lane);
-    for (uint64_t off = c0; off < c1; off += 1024) {
-        const uint32_t cur = unp_m16(p, off + 16u * lane, raw);
-        if (off + 1024 < c1) raw = unp_load16(p, off + 1024 + 16u * lane); // in flight during the parse
-        unp_spec_block<0>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<1>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<2>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<3>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<4>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<5>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<6>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<7>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<8>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<9>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<10>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<11>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<12>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<13>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<14>(p, cur, off, c1, lane, S, state, n, merged);
-        unp_spec_block<15>(p, cur, off, c1, lane, S, state, n, merged);
+    const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
+    const uint64_t a1 = min(p.nbytes, a0 + p.piece_bytes); // a1 <= a0: the piece is empty
+    for (uint32_t x = 0; x < S; x++) {
+        sst[x * 65 + lane] = (x == V + 1) ? UNP_INKEY : x;
+        scn[x * 65 + lane] = 0;
     }
-    if ((uint32_t) lane < S) {
-        // exit state as an index: 0..V, or V+1 for "inside a key" (at most V bytes are
-        // ever owed after a NUL)
-        const uint32_t e = (state & UNP_INKEY) ? p.V + 1 : state;
-        p.exit_state[(uint64_t) c * S + lane] = (uint8_t) e;
-        p.count[(uint64_t) c * S + lane] = n;
+    bool merged = false; // every entry state of this lane has led to the same state
+    uint32_t state = 0, dn = 0;
+    const uint32_t nb = p.piece_bytes / 64;
+    UnpRows rows;
+    unp_rows_load(p, c0, 0, lane, rows);
+    for (uint32_t b = 0; b < nb; b++) {
+        const UnpRows cur = rows;
+        if (b + 1 < nb) unp_rows_load(p, c0, b + 1, lane, rows); // in flight during the parse
+        const uint64_t nul = unp_rows_mask(p, c0, b, lane, cur, smask);
+        const uint64_t boff = a0 + 64u * b;
+        if (boff >= a1) continue;
+        const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
+        if (merged) {
+            state = unp_step(nul, state, V, valid, [&](uint32_t) { dn++; });
+            continue;
+        }
+        uint32_t prev_in = 0xFFFFFFFFu, out = 0, dnx = 0, first = 0;
+        bool same = true;
+        for (uint32_t x = 0; x < S; x++) {
+            const uint32_t st = sst[x * 65 + lane];
+            if (st != prev_in) {
+                dnx = 0;
+                out = unp_step(nul, st, V, valid, [&](uint32_t) { dnx++; });
+                prev_in = st;
+            }
+            sst[x * 65 + lane] = out;
+            scn[x * 65 + lane] += dnx;
+            if (x == 0) first = out;
+            else same = same && out == first;
+        }
+        if (same) {
+            merged = true;
+            state = first;
+        }
+    }
+    for (uint32_t x = 0; x < S; x++) {
+        const uint32_t e = merged ? state : sst[x * 65 + lane];
+        sst[x * 65 + lane] = (e & UNP_INKEY) ? V + 1 : e; // at most V bytes are ever owed after a NUL
+        if (merged) scn[x * 65 + lane] += dn;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < UNP_PIECES * S; i += 64) {
+        const uint32_t piece = i / S, x = i - piece * S;
+        p.piece_exit[(uint64_t) c * UNP_PIECES * S + i] = (uint8_t) sst[x * 65 + piece];
+        p.piece_count[(uint64_t) c * UNP_PIECES * S + i] = (uint16_t) scn[x * 65 + piece];
+    }
+    if ((uint32_t) lane < S) { // the chunk's table: entry state `lane` through the 64 pieces
+        uint32_t cur = lane, cnt = 0;
+        for (int piece = 0; piece < UNP_PIECES; piece++) {
+            cnt += scn[cur * 65 + piece];
+            cur = sst[cur * 65 + piece];
+        }
+        p.exit_state[(uint64_t) c * S + lane] = (uint8_t) cur;
+        p.count[(uint64_t) c * S + lane] = cnt;
     }
 }
 
@@ -268,53 +290,94 @@ __global__ __launch_bounds__(64) void k_unp_chain(UnpParams p)
     }
 }
 
-template <int B>
-__device__ __forceinline__ void unp_emit_block(const UnpParams &p, uint32_t m16, uint64_t off, uint64_t c1,
-                                               int lane, uint32_t &state, uint64_t &idx)
-{
-    const uint64_t boff = off + 64u * B;
-    if (boff >= c1) return;
-    const uint64_t nul = unp_block_mask<B>(m16);
-    const uint32_t valid = (uint32_t) min((uint64_t) 64, c1 - boff);
-    uint64_t starts = 0;
-    uint32_t n = 0;
-    state = unp_step(nul, state, p.V, valid, starts, n); // the same in every lane
-    if ((starts >> lane) & 1ull)
-        p.rec_off[idx + (uint32_t) __popcll(starts & ((1ull << lane) - 1ull))] = (uint32_t) (boff + lane);
-    idx += n;
-}
+// A lane's record starts are consecutive entries of rec_off, a few per step, and
+// the 64 lanes write to 64 places: stored one by one every store instruction
+// touches 64 lines for 4 bytes each.  So a lane collects its entries in LDS, in
+// groups of 16 that are 64-byte groups of rec_off (counted from a 16-byte
+// boundary at or below rec_off), and writes a group with four 16-byte stores
+// when it is complete; the entries of a group that the lane shares with its
+// neighbour (the first and the last of its piece) go one by one.
+constexpr int UNP_SLOT_PITCH = 20; // dwords per lane: 16 entries, padded so that 16-byte reads of 8 lanes fill the banks
 
+struct UnpSink {
+    uint32_t *slot;    // this lane's 16 entries in LDS
+    uint32_t *out;     // rec_off moved back to a 16-byte boundary
+    uint64_t v;        // next entry to write, counted from `out`
+    uint64_t v_first;  // first entry of this lane
+
+    __device__ __forceinline__ void put(uint32_t value)
+    {
+        slot[(uint32_t) v & 15u] = value;
+        v++;
+        if (((uint32_t) v & 15u) == 0) flush_group();
+    }
+    __device__ __forceinline__ void flush_group() // the group that ends at v
+    {
+        const uint64_t g = v - 16;
+        if (g >= v_first) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(slot);
+            uint4 *dst = reinterpret_cast<uint4 *>(out + g);
+#pragma unroll
+            for (int i = 0; i < 4; i++) dst[i] = src[i];
+        }
+        else {
+            for (uint32_t e = (uint32_t) v_first & 15u; e < 16; e++) out[g + e] = slot[e];
+        }
+    }
+    __device__ __forceinline__ void finish() // the incomplete last group
+    {
+        const uint64_t g = v & ~(uint64_t) 15;
+        for (uint64_t i = max(g, v_first); i < v; i++) out[i] = slot[(uint32_t) i & 15u];
+    }
+};
+
+// Dynamic LDS: the chunk's piece tables as (exit << 16 | count) [64][S], the 256
+// block masks, the lanes' entry groups.
 __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
 {
+    extern __shared__ uint32_t unp_lds[];
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = blockIdx.x, V = p.V, S = V + 2;
     if (p.ctrl->head.error != 0) return;
+    uint32_t *stab = unp_lds;
+    uint16_t *smask = reinterpret_cast<uint16_t *>(unp_lds + UNP_PIECES * S);
     const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
-    const uint64_t c1 = min(p.nbytes, c0 + p.chunk_bytes);
-    const uint32_t e = p.entry[c];
-    uint32_t state = (e == p.V + 1) ? UNP_INKEY : e;
-    uint64_t idx = p.first_rec[c];
-    uint4 raw = unp_load16(p, c0 + 16u * lane);
-    for (uint64_t off = c0; off < c1; off += 1024) {
-        const uint32_t cur = unp_m16(p, off + 16u * lane, raw);
-        if (off + 1024 < c1) raw = unp_load16(p, off + 1024 + 16u * lane); // in flight during the parse
-        unp_emit_block<0>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<1>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<2>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<3>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<4>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<5>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<6>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<7>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<8>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<9>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<10>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<11>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<12>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<13>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<14>(p, cur, off, c1, lane, state, idx);
-        unp_emit_block<15>(p, cur, off, c1, lane, state, idx);
+    const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
+    const uint64_t a1 = min(p.nbytes, a0 + p.piece_bytes);
+    const uint32_t nb = p.piece_bytes / 64;
+    UnpRows rows;
+    unp_rows_load(p, c0, 0, lane, rows);
+    for (uint32_t i = lane; i < UNP_PIECES * S; i += 64)
+        stab[i] = ((uint32_t) p.piece_exit[(uint64_t) c * UNP_PIECES * S + i] << 16)
+                  | p.piece_count[(uint64_t) c * UNP_PIECES * S + i];
+    __syncthreads();
+    // the chunk's entry state through the pieces, the same walk in every lane
+    uint32_t cur = p.entry[c], cnt = 0, mine = 0, base = 0;
+    for (int piece = 0; piece < UNP_PIECES; piece++) {
+        if (piece == lane) {
+            mine = cur;
+            base = cnt;
+        }
+        const uint32_t t = stab[piece * S + cur];
+        cnt += t & 0xFFFFu;
+        cur = t >> 16;
     }
+    uint32_t state = (mine == V + 1) ? UNP_INKEY : mine;
+    const uint32_t back = (uint32_t) ((reinterpret_cast<uintptr_t>(p.rec_off) >> 2) & 3u);
+    UnpSink sink;
+    sink.slot = unp_lds + ((UNP_PIECES * S + 128 + 3) & ~3u) + UNP_SLOT_PITCH * lane;
+    sink.out = p.rec_off - back;
+    sink.v = sink.v_first = p.first_rec[c] + base + back;
+    for (uint32_t b = 0; b < nb; b++) {
+        const UnpRows now = rows;
+        if (b + 1 < nb) unp_rows_load(p, c0, b + 1, lane, rows); // in flight during the parse
+        const uint64_t nul = unp_rows_mask(p, c0, b, lane, now, smask);
+        const uint64_t boff = a0 + 64u * b;
+        if (boff >= a1) continue;
+        const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
+        state = unp_step(nul, state, V, valid, [&](uint32_t pos) { sink.put((uint32_t) boff + pos); });
+    }
+    sink.finish();
     if (c == p.nchunks - 1 && lane == 0) p.rec_off[p.first_rec[p.nchunks]] = (uint32_t) p.nbytes;
 }
 

@@ -130,3 +130,38 @@ def test_unpack_errors(oracle):
         unpack_stream(pk, d, len(good))
     assert ei.value.status == capi.ERR_ARG
     pk.close()
+
+
+@pytest.mark.parametrize("shift_off,shift_stream", [(1, 0), (2, 3), (3, 5), (0, 9)])
+def test_unpack_unaligned_buffers_and_canaries(oracle, shift_off, shift_stream):
+    """Offsets buffer and stream at odd addresses; nothing is written outside
+    rec_off[0..n] (the kernel stores 16 bytes at a time inside that range)."""
+    from mimir_amd.packer import unpack_stream
+    n = 150000
+    blob, offs, lay = datagen.word_records(n, n_unique=3000, alpha=0.8, len_mean=5, len_sd=2, seed=77 + shift_off)
+    torch, pk, olay = _setup(lay)
+    want = oracle.parse_records(olay, blob)
+    raw = torch.empty(len(blob) + 64, dtype=torch.uint8, device="cuda")
+    d = raw[shift_stream:shift_stream + len(blob)]
+    d.copy_(torch.from_numpy(np.ascontiguousarray(blob)))
+    pad = 64
+    buf = torch.full((n + 1 + 2 * pad + 4,), -7, dtype=torch.int32, device="cuda")
+    view = buf[pad + shift_off:pad + shift_off + n + 1]
+    rec_off, got_n, _ = unpack_stream(pk, d, len(blob), rec_off=view)
+    assert got_n == n
+    host = buf.cpu().numpy()
+    assert np.array_equal(host[pad + shift_off:pad + shift_off + n + 1].view(np.uint32).astype(np.uint64), want)
+    assert (host[:pad + shift_off] == -7).all() and (host[pad + shift_off + n + 1:] == -7).all()
+    pk.close()
+
+
+def test_unpack_states_that_never_meet(oracle):
+    """A stream of zeros: records of an empty key and an all-zero value.  Every
+    entry state stays on its own track for the whole stream."""
+    n = 400000
+    blob = np.zeros(9 * n, dtype=np.uint8)
+    got_n, _ = check(oracle, blob, (capi.KEY_CSTR, 0, capi.VAL_FIXED, 8), 1 << 16)
+    assert got_n == n
+    blob = np.zeros(63 * 5000, dtype=np.uint8)
+    got_n, _ = check(oracle, blob, (capi.KEY_CSTR, 0, capi.VAL_FIXED, 62), 1 << 16)
+    assert got_n == 5000
