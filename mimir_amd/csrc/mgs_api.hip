@@ -721,7 +721,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     const size_t tables = (size_t) p.nchunks * UNP_PIECES * S;
     const size_t need = up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t))
                         + up(((size_t) p.nchunks + 1) * sizeof(uint64_t)) + up((size_t) p.nchunks * S * sizeof(uint32_t))
-                        + up((size_t) p.nchunks * sizeof(uint32_t)) + up((size_t) p.nchunks * S)
+                        + up((size_t) p.nchunks * sizeof(uint32_t))
                         + up(tables * sizeof(uint16_t)) + up(tables);
     if (h->pending) { // one call in flight per handle: the control block and the scratch are shared
         MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
@@ -741,9 +741,8 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     p.result = reinterpret_cast<uint64_t *>(q); // result and cuts leave with one copy
     p.cuts = p.result + 2;                                    q += up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t));
     p.first_rec = reinterpret_cast<uint64_t *>(q);            q += up(((size_t) p.nchunks + 1) * sizeof(uint64_t));
-    p.count = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * S * sizeof(uint32_t));
+    p.table = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * S * sizeof(uint32_t));
     p.entry = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * sizeof(uint32_t));
-    p.exit_state = q;                                         q += up((size_t) p.nchunks * S);
     p.piece_count = reinterpret_cast<uint16_t *>(q);          q += up(tables * sizeof(uint16_t));
     p.piece_exit = q;                                         q += up(tables);
     p.rec_off = d_rec_off;
@@ -771,7 +770,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
         const size_t lds_spec = (2 * (size_t) S * 65 + 128) * sizeof(uint32_t);
         const size_t lds_emit = ((((size_t) UNP_PIECES * S + 128 + 3) & ~(size_t) 3) + 64 * UNP_SLOT_PITCH) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_unp_spec, dim3(p.nchunks), dim3(64), lds_spec, stream, p);
-        hipLaunchKernelGGL(k_unp_chain, dim3(1), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_unp_chain, dim3(1), dim3(64 * UNP_CHAIN_WAVES), 0, stream, p);
         hipLaunchKernelGGL(k_unp_emit, dim3(p.nchunks), dim3(64), lds_emit, stream, p);
     }
     hipLaunchKernelGGL(k_unp_pages, dim3(1), dim3(64), 0, stream, p);

@@ -53,8 +53,7 @@ struct UnpParams {
     uint32_t chunk_bytes; // 64 pieces
     uint32_t piece_bytes; // multiple of 64, below 65536 (record counts of a piece are 16-bit)
     uint32_t nchunks;
-    uint8_t *exit_state;  // [nchunks][V+2]
-    uint32_t *count;      // [nchunks][V+2]
+    uint32_t *table;      // [nchunks][V+2]: exit state << 24 | records, per entry state
     uint8_t *piece_exit;  // [nchunks][64][V+2]
     uint16_t *piece_count; // [nchunks][64][V+2]
     uint32_t *entry;      // [nchunks] entry state of each chunk
@@ -229,35 +228,67 @@ __global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
             cnt += scn[cur * 65 + piece];
             cur = sst[cur * 65 + piece];
         }
-        p.exit_state[(uint64_t) c * S + lane] = (uint8_t) cur;
-        p.count[(uint64_t) c * S + lane] = cnt;
+        p.table[(uint64_t) c * S + lane] = (cur << 24) | cnt; // a chunk is at most 2^21 bytes
     }
 }
 
-// One wave follows the chain through the chunks: lane x holds the table row entry
-// (exit state, count) for state x of the chunk at hand; the rows of 16 chunks are
-// fetched at once (their addresses do not depend on the chain), a step is two
-// register reads, and the 16 results leave with one store.
-__global__ __launch_bounds__(64) void k_unp_chain(UnpParams p)
+// The chain through the chunks.  A chunk's table is a function from entry state
+// to (exit state, records) and the chain is their composition, so it is cut
+// into 16 runs, one wave each:
+//   1. lane x follows entry state x through the wave's run (a row of the table
+//      per chunk in registers, lane x holding entry x; a step is one shuffle);
+//   2. the run tables go through LDS, every wave follows state 0 through the
+//      runs before its own -> its entry state and first record;
+//   3. the wave follows that one state through its run again (a step is two
+//      register reads) and writes entry state and first record of every chunk.
+// Rows are fetched a batch ahead: their addresses do not depend on the chain.
+constexpr int UNP_CHAIN_WAVES = 16;
+
+__global__ __launch_bounds__(64 * UNP_CHAIN_WAVES) void k_unp_chain(UnpParams p)
 {
-    const int lane = threadIdx.x;
+    __shared__ uint32_t run_exit[UNP_CHAIN_WAVES][64];
+    __shared__ uint64_t run_count[UNP_CHAIN_WAVES][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t S = p.V + 2;
-    constexpr int BATCH = 16;
+    constexpr int BATCH = 32;
+    const uint32_t per = (p.nchunks + UNP_CHAIN_WAVES - 1) / UNP_CHAIN_WAVES;
+    const uint32_t cbeg = min(p.nchunks, (uint32_t) w * per), cend = min(p.nchunks, cbeg + per);
+    const uint32_t x = min((uint32_t) lane, S - 1);
+    auto fetch = [&](uint32_t c0, uint32_t (&row)[BATCH]) {
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) row[j] = p.table[(uint64_t) min(c0 + j, p.nchunks - 1) * S + x];
+    };
+    uint32_t row[BATCH], ahead[BATCH];
+    {
+        uint32_t cur = x;
+        uint64_t cnt = 0;
+        if (cbeg < cend) fetch(cbeg, row);
+        for (uint32_t c0 = cbeg; c0 < cend; c0 += BATCH) {
+            if (c0 + BATCH < cend) fetch(c0 + BATCH, ahead);
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) {
+                if (c0 + j < cend) {
+                    const uint32_t t = (uint32_t) __shfl((int) row[j], (int) cur);
+                    cnt += t & 0xFFFFFFu;
+                    cur = t >> 24;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) row[j] = ahead[j];
+        }
+        run_exit[w][lane] = cur;
+        run_count[w][lane] = cnt;
+    }
+    if (cbeg < cend) fetch(cbeg, row); // for the second pass, in flight across the barrier
+    __syncthreads();
     uint32_t state = 0; // the stream starts at a record boundary
     uint64_t total = 0;
-    const uint32_t x = min((uint32_t) lane, S - 1);
-    auto fetch = [&](uint32_t c0, uint32_t (&ex)[BATCH], uint32_t (&cn)[BATCH]) {
-#pragma unroll
-        for (int j = 0; j < BATCH; j++) {
-            const uint32_t c = min(c0 + j, p.nchunks - 1);
-            ex[j] = p.exit_state[(uint64_t) c * S + x];
-            cn[j] = p.count[(uint64_t) c * S + x];
-        }
-    };
-    uint32_t ex[BATCH], cn[BATCH], ex2[BATCH], cn2[BATCH];
-    fetch(0, ex, cn);
-    for (uint32_t c0 = 0; c0 < p.nchunks; c0 += BATCH) {
-        if (c0 + BATCH < p.nchunks) fetch(c0 + BATCH, ex2, cn2); // in flight during this batch
+    for (int r = 0; r < w; r++) {
+        total += run_count[r][state];
+        state = run_exit[r][state];
+    }
+    for (uint32_t c0 = cbeg; c0 < cend; c0 += BATCH) {
+        if (c0 + BATCH < cend) fetch(c0 + BATCH, ahead);
         uint32_t my_entry = 0;
         uint64_t my_first = 0;
 #pragma unroll
@@ -266,22 +297,20 @@ __global__ __launch_bounds__(64) void k_unp_chain(UnpParams p)
                 my_entry = state;
                 my_first = total;
             }
-            if (c0 + j < p.nchunks) {
-                total += (uint32_t) __builtin_amdgcn_readlane((int) cn[j], (int) state);
-                state = (uint32_t) __builtin_amdgcn_readlane((int) ex[j], (int) state);
+            if (c0 + j < cend) {
+                const uint32_t t = (uint32_t) __builtin_amdgcn_readlane((int) row[j], (int) state);
+                total += t & 0xFFFFFFu;
+                state = t >> 24;
             }
         }
-        if (lane < BATCH && c0 + lane < p.nchunks) {
+        if (lane < BATCH && c0 + lane < cend) {
             p.entry[c0 + lane] = my_entry;
             p.first_rec[c0 + lane] = my_first;
         }
 #pragma unroll
-        for (int j = 0; j < BATCH; j++) {
-            ex[j] = ex2[j];
-            cn[j] = cn2[j];
-        }
+        for (int j = 0; j < BATCH; j++) row[j] = ahead[j];
     }
-    if (lane == 0) {
+    if (w == UNP_CHAIN_WAVES - 1 && lane == 0) { // the last run ends the stream (an empty run passes its entry on)
         p.first_rec[p.nchunks] = total;
         p.result[0] = total;
         // the stream must end at a record boundary: nothing owed, not inside a key
@@ -396,11 +425,14 @@ __global__ void k_unp_fixed(UnpParams p, uint32_t width)
 
 // KVContainer::write, src/kvcontainer.h:133-160: a record goes to the current
 // page if it fits exactly or with room to spare, else a new page is opened.
-__global__ void k_unp_pages(UnpParams p)
+// One wave: the last record that still fits is found by a search that probes 64
+// places at a time.
+__global__ __launch_bounds__(64) void k_unp_pages(UnpParams p)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
     if (p.ctrl->head.error != 0) {
-        p.result[1] = 0;
+        if (lane == 0) p.result[1] = 0;
         return;
     }
     const uint64_t n = p.result[0];
@@ -408,20 +440,24 @@ __global__ void k_unp_pages(UnpParams p)
     uint64_t room = S - (uint64_t) p.first_fill; // bytes left in the current page
     uint64_t i = 0, ncuts = 0;
     while (i < n) {
-        // largest j in (i, n] with rec_off[j] - rec_off[i] <= room
+        // largest j in [i, n] with rec_off[j] - rec_off[i] <= room
         const uint64_t base = p.rec_off[i];
         uint64_t lo = i, hi = n;
         while (lo < hi) {
-            const uint64_t mid = (lo + hi + 1) >> 1;
-            if ((uint64_t) p.rec_off[mid] - base <= room) lo = mid;
-            else hi = mid - 1;
+            const uint64_t step = (hi - lo + 63) / 64;
+            const uint64_t probe = min(hi, lo + (uint64_t) (lane + 1) * step);
+            const bool fits = (uint64_t) p.rec_off[probe] - base <= room;
+            const uint64_t k = (uint64_t) __popcll(__ballot(fits)); // the offsets ascend: the first k probes fit
+            const uint64_t nlo = min(hi, lo + k * step);
+            hi = min(hi, lo + (k + 1) * step - 1);
+            lo = nlo;
         }
         if (lo == n) break;
         if (lo == i && room == S) { // does not fit an empty page (:147-149)
-            raise_error(p.ctrl, MGS_ERR_RECORD_SIZE);
+            if (lane == 0) raise_error(p.ctrl, MGS_ERR_RECORD_SIZE);
             break;
         }
-        if (ncuts < p.max_cuts) {
+        if (ncuts < p.max_cuts && lane == 0) {
             p.cuts[2 * ncuts] = lo;
             p.cuts[2 * ncuts + 1] = p.rec_off[lo];
         }
@@ -429,7 +465,7 @@ __global__ void k_unp_pages(UnpParams p)
         i = lo;
         room = S;
     }
-    p.result[1] = ncuts;
+    if (lane == 0) p.result[1] = ncuts;
 }
 
 } // namespace mgs

@@ -1,9 +1,11 @@
 // Debug aid: is a lane-divergent parse loop deterministic on gfx950?
 // Lane x of each wave parses the wave's chunk from entry state x, every lane
 // walking the same 64-bit NUL masks with its own position.  Variant 0 leaves the
-// loop with an early return (the form that gave wrong counts now and then),
-// variant 1 has a single loop exit.  Both are run repeatedly and compared with a
-// host replay.
+// loop with an early return, variant 1 has a single loop exit.  Both are run
+// repeatedly and compared with a host replay.  Usage: div_check [first variant] [reps]
+// Seen so far: both variants agree with the host on every launch but, now and
+// then, the very first launch of a process on a fresh box, where one chunk's
+// counts are those of a stretch of zero bytes -- the upload, not the loop.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
