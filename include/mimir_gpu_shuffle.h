@@ -222,6 +222,34 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes,
                       uint64_t *n_records, mgs_page_cut *cuts, int max_cuts,
                       int *n_cuts, void *stream);
 
+/* ---- map side of wordcount: text -> <word, count> records ------------------
+ * What precedes the path in the reference for text inputs: FileReader::read
+ * frames the input into lines (FileParser::to_line cuts at '\n',
+ * src/fileparser.h:21-41; the reader advances by strlen + 1,
+ * src/filereader.h:138-183, so a NUL ends a line too) and the map callback
+ * splits each line at spaces with strtok_r and writes <word, 1> for every word
+ * shorter than 1024 bytes (examples/wordcount.cpp:66-82).  This call does the
+ * same on a device-resident text and leaves the records in wire form (word,
+ * NUL, 8 value bytes: src/serializer.h:63-83, :157-168), in text order, with
+ * their offsets -- the input form of mgs_pack_device:
+ *
+ *   d_text / nbytes     whole lines (the last one need not end with '\n');
+ *                       nbytes < 4 GiB
+ *   value               the value written with every word (wordcount: 1)
+ *   d_records           out, device: the records back to back;
+ *                       records_capacity bytes available (text bytes + 9 per
+ *                       word at most: 5 * nbytes + 9 always suffices)
+ *   d_rec_off           out, device: d_rec_off[i] = first byte of record i,
+ *                       d_rec_off[n] = total bytes; rec_off_capacity entries
+ *                       (nbytes / 2 + 2 always suffice)
+ *
+ * The handle's layout must be one NUL-terminated key and an 8-byte value.
+ * MGS_ERR_ARG when an output does not fit or would pass 4 GiB.  Blocking. */
+int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes,
+                        uint64_t value, void *d_records, uint64_t records_capacity,
+                        uint32_t *d_rec_off, uint64_t rec_off_capacity,
+                        uint64_t *n_records, uint64_t *n_bytes, void *stream);
+
 /* ---- host-staged front end: what a Writable::write() shim calls -----------
  * The reference serialises every pair into the send buffer inside write()
  * (src/collectiveshuffler.h:143-146) because the caller's pointers die when

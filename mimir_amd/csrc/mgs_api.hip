@@ -18,6 +18,7 @@
 #include "mgs_onesweep16w.h"
 #include "mgs_onesweepv.h"
 #include "mgs_unpack.h"
+#include "mgs_tokenize.h"
 
 using namespace mgs;
 
@@ -675,6 +676,22 @@ int mgs_get_desc(const mgs_handle *h, mgs_desc *out)
 constexpr uint32_t kUnpMaxCuts = 4096;
 constexpr size_t kUnpScratch = 8u << 20; // first allocation; grows with the stream
 
+// Scratch of the blocking parse calls (unpack, tokenize): one buffer per handle.
+static int ensure_unp_scratch(mgs_handle *h, size_t need)
+{
+    if (need <= h->unp_bytes) return MGS_OK;
+    if (h->d_unp) {
+        MGS_HIP(h, hipDeviceSynchronize());
+        MGS_HIP(h, hipFree(h->d_unp));
+        h->d_unp = nullptr;
+        h->unp_bytes = 0;
+    }
+    const size_t want = std::max(need, kUnpScratch);
+    MGS_HIP(h, hipMalloc(&h->d_unp, want));
+    h->unp_bytes = want;
+    return MGS_OK;
+}
+
 int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint32_t *d_rec_off,
                       uint64_t rec_off_capacity, int64_t page_bytes, int64_t first_page_fill,
                       uint64_t *n_records, mgs_page_cut *cuts, int max_cuts, int *n_cuts, void *stream_v)
@@ -726,17 +743,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     if (h->pending) { // one call in flight per handle: the control block and the scratch are shared
         MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
     }
-    if (need > h->unp_bytes) {
-        if (h->d_unp) {
-            MGS_HIP(h, hipDeviceSynchronize());
-            MGS_HIP(h, hipFree(h->d_unp));
-            h->d_unp = nullptr;
-            h->unp_bytes = 0;
-        }
-        const size_t want = std::max(need, kUnpScratch);
-        MGS_HIP(h, hipMalloc(&h->d_unp, want));
-        h->unp_bytes = want;
-    }
+    { const int rc = ensure_unp_scratch(h, need); if (rc) return rc; }
     uint8_t *q = h->d_unp;
     p.result = reinterpret_cast<uint64_t *>(q); // result and cuts leave with one copy
     p.cuts = p.result + 2;                                    q += up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t));
@@ -801,6 +808,87 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
         cuts[k].first_byte = h->h_unp[3 + 2 * k];
     }
     *n_cuts = (int) nc;
+    return MGS_OK;
+}
+
+// ---- map side of wordcount --------------------------------------------------------
+int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint64_t value, void *d_records,
+                        uint64_t records_capacity, uint32_t *d_rec_off, uint64_t rec_off_capacity,
+                        uint64_t *n_records, uint64_t *n_bytes, void *stream_v)
+{
+    if (!h || !d_rec_off || !n_records || !n_bytes || (nbytes && !d_text) || (records_capacity && !d_records)) {
+        if (h) h->err = "mgs_tokenize_device: NULL argument";
+        return MGS_ERR_ARG;
+    }
+    const mgs_layout &L = h->desc.layout;
+    if (L.key_kind != MGS_KEY_CSTR || L.key_count != 1 || L.val_kind != MGS_VAL_FIXED || L.val_bytes != 8) {
+        h->err = "mgs_tokenize_device: the layout must be one string key and an 8-byte value";
+        return MGS_ERR_ARG;
+    }
+    if (nbytes >= (1ull << 32) || rec_off_capacity == 0) {
+        h->err = "mgs_tokenize_device: text must be under 4 GiB, rec_off_capacity > 0";
+        return MGS_ERR_ARG;
+    }
+    DeviceGuard g(h->desc.device);
+    if (!g.ok) {
+        h->err = "mgs_tokenize_device: hipSetDevice failed";
+        return MGS_ERR_HIP;
+    }
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
+    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
+
+    TokParams p;
+    memset(&p, 0, sizeof(p));
+    p.text = static_cast<const uint8_t *>(d_text);
+    p.nbytes = nbytes;
+    // one wave per chunk, one lane per piece; the end of the text (position nbytes) is
+    // covered too: it closes an open word
+    uint64_t chunk = (nbytes + 1 + UNP_MAX_CHUNKS - 1) / UNP_MAX_CHUNKS;
+    chunk = std::max<uint64_t>(16384, (chunk + 4095) / 4096 * 4096);
+    p.chunk_bytes = (uint32_t) chunk;
+    p.piece_bytes = (uint32_t) (chunk / UNP_PIECES);
+    p.nchunks = (uint32_t) ((nbytes + 1 + chunk - 1) / chunk);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t need = up(2 * sizeof(uint64_t)) + up((size_t) p.nchunks * 3 * 64 * sizeof(uint32_t))
+                        + up((size_t) p.nchunks * 3 * sizeof(uint32_t)) + up((size_t) p.nchunks * 3 * sizeof(uint64_t));
+    if (h->pending) { // one call in flight per handle: the control block and the scratch are shared
+        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    }
+    { const int rc = ensure_unp_scratch(h, need); if (rc) return rc; }
+    uint8_t *q = h->d_unp;
+    p.result = reinterpret_cast<uint64_t *>(q);    q += up(2 * sizeof(uint64_t));
+    p.chunk_x = reinterpret_cast<uint64_t *>(q);   q += up((size_t) p.nchunks * 3 * sizeof(uint64_t));
+    p.piece_x = reinterpret_cast<uint32_t *>(q);   q += up((size_t) p.nchunks * 3 * 64 * sizeof(uint32_t));
+    p.chunk_tot = reinterpret_cast<uint32_t *>(q); q += up((size_t) p.nchunks * 3 * sizeof(uint32_t));
+    p.out = static_cast<uint8_t *>(d_records);
+    p.out_cap = records_capacity;
+    p.rec_off = d_rec_off;
+    p.rec_cap = rec_off_capacity;
+    p.value = value;
+    p.ctrl = h->d_ctrl;
+
+    MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
+    const size_t lds_count = 128 * sizeof(uint32_t);
+    const size_t lds_emit = 128 * sizeof(uint32_t) + 3 * 64 * TOK_ROW_PITCH + 64 * UNP_SLOT_PITCH * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_tok_count, dim3(p.nchunks), dim3(64), lds_count, stream, p);
+    hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(k_tok_emit, dim3(p.nchunks), dim3(64), lds_emit, stream, p);
+    MGS_HIP(h, hipGetLastError());
+    MGS_HIP(h, hipMemcpyAsync(h->h_unp, p.result, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipMemcpyAsync(&h->h_ctrl->head.error, &h->d_ctrl->head.error, sizeof(int32_t),
+                              hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipStreamSynchronize(stream));
+    const int derr = h->h_ctrl->head.error;
+    if (derr != 0) {
+        if (derr == MGS_ERR_ARG)
+            h->err = fmt("mgs_tokenize_device: %llu records, %llu bytes do not fit the outputs (or pass 4 GiB)",
+                         (unsigned long long) h->h_unp[0], (unsigned long long) h->h_unp[1]);
+        else
+            h->err = fmt("device error %d", derr);
+        return derr;
+    }
+    *n_records = h->h_unp[0];
+    *n_bytes = h->h_unp[1];
     return MGS_OK;
 }
 

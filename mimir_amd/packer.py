@@ -165,6 +165,24 @@ def unpack_stream(packer, stream, nbytes, page_bytes=64 << 20, first_page_fill=0
                                    for i in range(ncuts.value)]
 
 
+def tokenize_text(packer, text, nbytes, value=1, records=None, rec_off=None):
+    """wordcount's map on the device: a device-resident text (uint8 tensor, whole
+    lines) -> (records uint8 tensor, rec_off int32 tensor, n_records, n_bytes), the
+    input form of DevicePacker.pack.  The packer's layout must be <string, 8 bytes>."""
+    if records is None:
+        records = torch.empty(max(16, nbytes + 9 * (nbytes // 2 + 1)), dtype=torch.uint8, device=text.device)
+    if rec_off is None:
+        rec_off = torch.empty(nbytes // 2 + 2, dtype=torch.int32, device=text.device)
+    n, nb = C.c_uint64(), C.c_uint64()
+    s = torch.cuda.current_stream(packer.device).cuda_stream
+    if not s:  # see DevicePacker._args
+        torch.cuda.current_stream(packer.device).synchronize()
+    packer._check(packer.lib.mgs_tokenize_device(
+        packer.h, _ptr(text), nbytes, value, _ptr(records), records.numel(), _ptr(rec_off),
+        rec_off.numel(), C.byref(n), C.byref(nb), C.c_void_p(s)))
+    return records, rec_off, int(n.value), int(nb.value)
+
+
 def synth_u64_records(n, seed=42, first=0, device=0, out=None):
     """n <u64,u64> records generated on the device (16*n bytes, uint8)."""
     if out is None:

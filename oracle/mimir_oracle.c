@@ -285,3 +285,47 @@ int64_t mo_page_cuts(const uint64_t *rec_off, int64_t n, int64_t page_bytes,
     }
     return ncuts;
 }
+
+int64_t mo_tokenize(const uint8_t *text, int64_t nbytes, uint64_t value,
+                    uint8_t *out, int64_t out_cap, uint64_t *rec_off_out,
+                    int64_t max_records)
+{
+    int64_t start = 0, win = nbytes, nrec = 0, opos = 0;
+    while (win > 0) {
+        /* to_line: the line ends at the first '\n' of the window; in the last
+         * block a line without one ends with the window (src/fileparser.h:25-38) */
+        int64_t line = 0;
+        while (line < win && text[start + line] != '\n') line++;
+        /* key_from_bytes of a char* key = strlen + 1 (src/serializer.h:193-205):
+         * the callback's line ends at the first NUL, and so does the reader's step */
+        int64_t len = 0;
+        while (len < line && text[start + len] != 0) len++;
+        /* strtok_r(line, " "): maximal runs of bytes other than ' ' */
+        int64_t i = 0;
+        while (i < len) {
+            while (i < len && text[start + i] == ' ') i++;
+            int64_t w0 = i;
+            while (i < len && text[start + i] != ' ') i++;
+            const int64_t wl = i - w0;
+            if (wl > 0 && wl < 1024) { /* examples/wordcount.cpp:72 */
+                if (nrec >= max_records || opos + wl + 9 > out_cap) return -1;
+                rec_off_out[nrec++] = (uint64_t) opos;
+                memcpy(out + opos, text + start + w0, (size_t) wl);
+                out[opos + wl] = 0;
+                memcpy(out + opos + wl + 1, &value, 8);
+                opos += wl + 9;
+            }
+        }
+        /* src/filereader.h:163-170: past the line's terminator, or the window is used up */
+        const int64_t move = len + 1;
+        if (move >= win) {
+            win = 0;
+        }
+        else {
+            start += move;
+            win -= move;
+        }
+    }
+    rec_off_out[nrec] = (uint64_t) opos;
+    return nrec;
+}

@@ -129,6 +129,20 @@ int64_t mo_page_cuts(const uint64_t *rec_off, int64_t n, int64_t page_bytes,
                      int64_t first_fill, uint64_t *cut_record_out,
                      int64_t max_cuts);
 
+/* Map side of wordcount: FileReader::read hands out the text line by line
+ * (FileParser::to_line cuts at the first '\n', or at the end of the last
+ * block: src/fileparser.h:21-41; the reader then advances by strlen + 1:
+ * src/filereader.h:152-171, so a NUL ends a line as well) and the map callback
+ * splits each line at spaces the way strtok_r does and writes <word, value>
+ * for words shorter than 1024 bytes (examples/wordcount.cpp:66-82) in wire form
+ * (word, NUL, 8 value bytes: src/serializer.h:63-83, :157-168).  The text is
+ * one last block: whole lines, the last one need not end with '\n'.
+ * Writes the records to out (capacity out_cap) and rec_off_out[0..n] (room for
+ * max_records + 1); returns n, or -1 when something does not fit. */
+int64_t mo_tokenize(const uint8_t *text, int64_t nbytes, uint64_t value,
+                    uint8_t *out, int64_t out_cap, uint64_t *rec_off_out,
+                    int64_t max_records);
+
 #ifdef __cplusplus
 }
 #endif

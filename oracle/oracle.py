@@ -86,7 +86,22 @@ class Oracle:
         L.mo_page_cuts.restype = C.c_int64
         L.mo_page_cuts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_int64]
+        L.mo_tokenize.restype = C.c_int64
+        L.mo_tokenize.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p,
+                                  C.c_int64, C.c_void_p, C.c_int64]
         self.L = L
+
+    def tokenize(self, text, value=1):
+        """wordcount's map over a text: (records uint8, rec_off uint64[n+1])."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        cap = 5 * len(text) + 16
+        out = np.zeros(cap, dtype=np.uint8)
+        offs = np.zeros(len(text) // 2 + 2, dtype=np.uint64)
+        n = self.L.mo_tokenize(text.ctypes.data, len(text), value, out.ctypes.data,
+                               cap, offs.ctypes.data, len(offs) - 1)
+        if n < 0:
+            raise ValueError("oracle: tokenize output does not fit")
+        return out[:int(offs[n])], offs[:n + 1]
 
     def page_cuts(self, rec_off, page_bytes, first_fill=0):
         """Indices of the records that open a new container page."""
@@ -196,7 +211,24 @@ class Reference:
                                          C.c_int]
         L.ref_key_size_cstr.restype = C.c_int
         L.ref_key_size_cstr.argtypes = [C.c_char_p]
+        L.ref_wordcount_map.restype = C.c_long
+        L.ref_wordcount_map.argtypes = [C.c_void_p, C.c_long, C.c_uint64, C.c_void_p,
+                                        C.c_long, C.c_void_p, C.c_long]
         self.L = L
+
+    def wordcount_map(self, text, value=1):
+        """The reference's own line framing + serialisation over a text."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        work = np.zeros(len(text) + 8, dtype=np.uint8)  # modified in place, one spare byte
+        work[:len(text)] = text
+        cap = 5 * len(text) + 16
+        out = np.zeros(cap, dtype=np.uint8)
+        offs = np.zeros(len(text) // 2 + 2, dtype=np.uint64)
+        n = self.L.ref_wordcount_map(work.ctypes.data, len(text), value, out.ctypes.data,
+                                     cap, offs.ctypes.data, len(offs) - 1)
+        if n < 0:
+            raise ValueError("reference: output does not fit")
+        return out[:int(offs[n])], offs[:n + 1]
 
     def hashlittle(self, data: bytes, initval=0, misalign=0):
         """Hash `data` placed `misalign` bytes past an 8-aligned address, so

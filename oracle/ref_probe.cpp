@@ -2,6 +2,7 @@
 // sources where they lie under /root/reference (never copied):
 //   * hashlittle()                     src/hash.cpp:152
 //   * bytestream<T>::to_bytes / size   src/serializer.h:40-223
+//   * FileParser::to_line              src/fileparser.h:21-41
 // Only the header-only, allocation-free static members of serializer.h are
 // instantiated, so nothing from the reference's memory.cpp / mimir.cpp (which
 // need the configure-generated mimir_config.h) is required.
@@ -15,6 +16,7 @@
 #include "hash.h"
 #include "memory.h"
 #include "serializer.h"
+#include "fileparser.h"
 
 using namespace MIMIR_NS;
 
@@ -77,6 +79,46 @@ int ref_key_size_cstr(const char *key)
 {
     char *k = const_cast<char *>(key);
     return bytestream<char *>::size(&k, 1);
+}
+
+// The text of one last block through the REAL FileParser::to_line and the
+// reader's own stepping rule (src/filereader.h:152-171: advance by the char*
+// key's size = strlen + 1, window used up when the step reaches its end), each
+// line split with strtok_r and serialised with the REAL bytestream templates as
+// examples/wordcount.cpp:66-82 does.  `text` must have one spare byte after
+// nbytes (to_line terminates an unterminated last line there) and is modified.
+long ref_wordcount_map(char *text, long nbytes, uint64_t value, char *out, long out_cap,
+                       uint64_t *rec_off_out, long max_records)
+{
+    FileParser parser;
+    long start = 0, win = nbytes, nrec = 0, opos = 0;
+    while (win > 0 && parser.to_line(text + start, (int) win, true) != -1) {
+        char *line = text + start;
+        const long move = (long) bytestream<char *>::size(&line, 1);
+        char *saveptr = NULL;
+        char *word = strtok_r(line, " ", &saveptr);
+        while (word != NULL) {
+            if (strlen(word) < 1024) {
+                if (nrec >= max_records) return -1;
+                int kb = bytestream<char *>::to_bytes(&word, 1, out + opos, (int) (out_cap - opos));
+                if (kb == -1) return -1;
+                int vb = bytestream<uint64_t>::to_bytes(&value, 1, out + opos + kb, (int) (out_cap - opos - kb));
+                if (vb == -1) return -1;
+                rec_off_out[nrec++] = (uint64_t) opos;
+                opos += kb + vb;
+            }
+            word = strtok_r(NULL, " ", &saveptr);
+        }
+        if (move >= win) {
+            win = 0;
+        }
+        else {
+            start += move;
+            win -= move;
+        }
+    }
+    rec_off_out[nrec] = (uint64_t) opos;
+    return nrec;
 }
 
 } // extern "C"

@@ -87,7 +87,23 @@ def main():
     with open(os.path.join(HERE, "wire_vectors.json"), "w") as f:
         json.dump({"source": "bytestream<T>::to_bytes, src/serializer.h:40-223",
                    "vectors": wire}, f, indent=0)
-    print(f"wrote {len(vectors)}+{len(seeded)} hash vectors, {len(wire)} wire vectors")
+    # 3. wordcount's map over small texts: FileParser::to_line framing, the reader's
+    #    strlen + 1 step, strtok_r split, bytestream serialisation.
+    texts = [b"", b"\n", b" ", b"a", b"a\n", b"hello world\n", b"  two  spaces \n\n end",
+             b"tab\tstays cr\r\n x", b"nul\0splits the line\nnext", b"\0\0 \n\0a",
+             b"x" * 1023 + b" " + b"y" * 1024 + b" z\n", b"w" * 2500, b"a b\n" * 40,
+             bytes(range(1, 256)) + b"\n"]
+    tok = []
+    for t in texts:
+        recs, offs = ref.wordcount_map(np.frombuffer(t, dtype=np.uint8), 1)
+        tok.append({"text_hex": t.hex(), "records_hex": bytes(recs).hex(),
+                    "rec_off": [int(x) for x in offs]})
+    with open(os.path.join(HERE, "tokenize_vectors.json"), "w") as f:
+        json.dump({"source": "FileParser::to_line (src/fileparser.h:21-41) + the reader's step "
+                             "(src/filereader.h:152-171) + strtok_r split and <word,1> write as in "
+                             "examples/wordcount.cpp:66-82, serialised by bytestream<T>::to_bytes",
+                   "vectors": tok}, f, indent=0)
+    print(f"wrote {len(vectors)}+{len(seeded)} hash vectors, {len(wire)} wire vectors, {len(tok)} texts")
 
 
 if __name__ == "__main__":
