@@ -869,7 +869,7 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint
 
     MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
     const size_t lds_count = 128 * sizeof(uint32_t);
-    const size_t lds_emit = 128 * sizeof(uint32_t) + 3 * 64 * TOK_ROW_PITCH + 64 * UNP_SLOT_PITCH * sizeof(uint32_t);
+    const size_t lds_emit = 128 * sizeof(uint32_t) + 2 * 64 * TOK_ROW_PITCH + 64 * UNP_SLOT_PITCH * sizeof(uint32_t);
     hipLaunchKernelGGL(k_tok_count, dim3(p.nchunks), dim3(64), lds_count, stream, p);
     hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(64), 0, stream, p);
     hipLaunchKernelGGL(k_tok_emit, dim3(p.nchunks), dim3(64), lds_emit, stream, p);

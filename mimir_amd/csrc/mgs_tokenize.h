@@ -136,18 +136,19 @@ __device__ __forceinline__ void tok_rows_load(const TokParams &p, uint64_t c0, u
 }
 
 // Word masks of the rows just loaded -> every lane's own 64-bit mask (through
-// LDS); with `rows_lds` the bytes themselves are left there too, row `r` at
-// rows_lds + r * TOK_ROW_PITCH.
+// LDS).  With `bytes`, the bytes of that (other) block b_bytes are handed to
+// their lanes on the way: row r at rows_lds + r * TOK_ROW_PITCH.
 __device__ __forceinline__ uint64_t tok_rows_mask(const TokParams &p, uint64_t c0, uint32_t b, int lane,
-                                                  const UnpRows &r, uint16_t *smask, uint8_t *rows_lds)
+                                                  const UnpRows &r, uint16_t *smask,
+                                                  const UnpRows *bytes = nullptr, uint32_t b_bytes = 0,
+                                                  uint8_t *rows_lds = nullptr)
 {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint64_t at = tok_row_at(p, c0, b, j, lane);
-        smask[64 * j + lane] = (uint16_t) tok_m16(p, at, r.raw[j]);
-        if (rows_lds)
+        smask[64 * j + lane] = (uint16_t) tok_m16(p, tok_row_at(p, c0, b, j, lane), r.raw[j]);
+        if (bytes)
             *reinterpret_cast<uint4 *>(rows_lds + (16 * j + (lane >> 2)) * TOK_ROW_PITCH + 16 * (lane & 3)) =
-                tok_in_place(p, at, r.raw[j]);
+                tok_in_place(p, tok_row_at(p, c0, b_bytes, j, lane), bytes->raw[j]);
     }
     __syncthreads();
     const uint64_t w = reinterpret_cast<const uint64_t *>(smask)[lane];
@@ -231,12 +232,12 @@ __global__ __launch_bounds__(64) void k_tok_count(TokParams p)
     uint32_t nbytes = 0, nclose = 0, nstart = 0;
     UnpRows rows;
     tok_rows_load(p, c0, 0, lane, rows);
-    uint64_t W = tok_rows_mask(p, c0, 0, lane, rows, smask, nullptr);
+    uint64_t W = tok_rows_mask(p, c0, 0, lane, rows, smask);
     tok_rows_load(p, c0, 1, lane, rows);
     for (uint32_t b = 0; b < nb; b++) {
         const UnpRows nxt = rows;
         if (b + 2 <= nb) tok_rows_load(p, c0, b + 2, lane, rows); // in flight during the walk
-        const uint64_t Wnext = tok_rows_mask(p, c0, b + 1, lane, nxt, smask, nullptr);
+        const uint64_t Wnext = tok_rows_mask(p, c0, b + 1, lane, nxt, smask);
         const TokBlock blk = tok_block(p, W, Wnext, a0 + 64u * b, st);
         nbytes += (uint32_t) __popcll(blk.keep);
         nclose += (uint32_t) __popcll(blk.closes);
@@ -281,25 +282,37 @@ __global__ __launch_bounds__(64) void k_tok_scan(TokParams p)
     }
 }
 
-// A lane's output bytes, collected in LDS in groups of 64 that are 64-byte
-// groups of the output (counted from a 16-byte boundary at or below `out`);
-// a complete group leaves with four 16-byte stores, the bytes of a group shared
-// with a neighbour one by one.
+// A lane's output bytes.  They are gathered eight at a time in a register and
+// collected in LDS in groups of 64 that are 64-byte groups of the output
+// (counted from a 16-byte boundary at or below `out`); a complete group leaves
+// with four 16-byte stores, the bytes of a group shared with a neighbour one by
+// one.
 struct TokSink {
     uint8_t *slot;
     uint8_t *out;     // moved back to a 16-byte boundary
     uint64_t v;       // next byte to write, counted from `out`
     uint64_t v_first; // first byte of this lane
+    uint64_t acc;     // the (v & 7) bytes of the current 8-byte unit that are there already
 
-    __device__ __forceinline__ void put(uint8_t b)
+    // the k low bytes of x (1 <= k <= 8, the bytes above them zero)
+    __device__ __forceinline__ void append(uint64_t x, uint32_t k)
     {
-        slot[(uint32_t) v & 63u] = b;
-        v++;
-        if (((uint32_t) v & 63u) == 0) flush_group();
+        const uint32_t fill = (uint32_t) v & 7u;
+        acc |= x << (8 * fill);
+        if (fill + k >= 8) {
+            const uint32_t unit = (uint32_t) v & 56u;
+            const uint64_t g = v & ~(uint64_t) 63;
+            *reinterpret_cast<uint64_t *>(slot + unit) = acc;
+            acc = fill ? x >> (8 * (8 - fill)) : 0ull;
+            v += k;
+            if (unit == 56u) flush_group(g); // the group's last unit
+        }
+        else {
+            v += k;
+        }
     }
-    __device__ __forceinline__ void flush_group()
+    __device__ __forceinline__ void flush_group(uint64_t g)
     {
-        const uint64_t g = v - 64;
         if (g >= v_first) {
             const uint4 *src = reinterpret_cast<const uint4 *>(slot);
             uint4 *dst = reinterpret_cast<uint4 *>(out + g);
@@ -312,13 +325,24 @@ struct TokSink {
     }
     __device__ __forceinline__ void finish()
     {
+        if ((uint32_t) v & 7u) *reinterpret_cast<uint64_t *>(slot + ((uint32_t) v & 56u)) = acc;
         const uint64_t g = v & ~(uint64_t) 63;
         for (uint64_t i = max(g, v_first); i < v; i++) out[i] = slot[(uint32_t) i & 63u];
     }
 };
 
-// Dynamic LDS: 256 block masks, two copies of the 64 lanes' blocks (this one and
-// the next), the lanes' output groups, the lanes' offset groups.
+// Eight bytes of a lane's block in LDS from byte `off` on (row: 8-byte aligned;
+// bytes up to off + 15 are read).
+__device__ __forceinline__ uint64_t tok_row_get8(const uint8_t *row, uint32_t off)
+{
+    const uint64_t *q = reinterpret_cast<const uint64_t *>(row + (off & ~7u));
+    const uint64_t lo = q[0], hi = q[1];
+    const uint32_t sh = 8u * (off & 7u);
+    return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+}
+
+// Dynamic LDS: 256 block masks, the 64 lanes' blocks, the lanes' output groups,
+// the lanes' offset groups.
 __global__ __launch_bounds__(64) void k_tok_emit(TokParams p)
 {
     extern __shared__ uint32_t tok_lds[];
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(64) void k_tok_emit(TokParams p)
     if (p.ctrl->head.error != 0) return;
     uint16_t *smask = reinterpret_cast<uint16_t *>(tok_lds);
     uint8_t *rows_lds = reinterpret_cast<uint8_t *>(tok_lds + 128);
-    uint8_t *bytes_lds = rows_lds + 2 * 64 * TOK_ROW_PITCH;
+    uint8_t *bytes_lds = rows_lds + 64 * TOK_ROW_PITCH;
     uint32_t *offs_lds = reinterpret_cast<uint32_t *>(bytes_lds + 64 * TOK_ROW_PITCH);
     const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
     const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
@@ -341,37 +365,54 @@ __global__ __launch_bounds__(64) void k_tok_emit(TokParams p)
     sink.slot = bytes_lds + TOK_ROW_PITCH * lane;
     sink.out = p.out - back;
     sink.v = sink.v_first = cx[0] + px[lane] + 9 * closed_before + back;
+    sink.acc = 0;
     UnpSink offs;
     const uint32_t oback = (uint32_t) ((reinterpret_cast<uintptr_t>(p.rec_off) >> 2) & 3u);
     offs.slot = offs_lds + UNP_SLOT_PITCH * lane;
     offs.out = p.rec_off - oback;
     offs.v = offs.v_first = cx[2] + px[128 + lane] + oback;
+    const uint8_t *mine = rows_lds + lane * TOK_ROW_PITCH;
+    const uint64_t tail0 = p.value << 8, tail1 = p.value >> 56; // NUL + value: 8 bytes, then 1
 
-    UnpRows rows;
-    tok_rows_load(p, c0, 0, lane, rows);
-    uint64_t W = tok_rows_mask(p, c0, 0, lane, rows, smask, rows_lds);
-    tok_rows_load(p, c0, 1, lane, rows);
+    UnpRows cur, nxt, ahead;
+    tok_rows_load(p, c0, 0, lane, cur);
+    uint64_t W = tok_rows_mask(p, c0, 0, lane, cur, smask);
+    tok_rows_load(p, c0, 1, lane, nxt);
     for (uint32_t b = 0; b < nb; b++) {
-        const UnpRows nxt = rows;
-        if (b + 2 <= nb) tok_rows_load(p, c0, b + 2, lane, rows); // in flight during the walk
-        const uint64_t Wnext = tok_rows_mask(p, c0, b + 1, lane, nxt, smask, rows_lds + ((b + 1) & 1u) * 64 * TOK_ROW_PITCH);
+        if (b + 2 <= nb) tok_rows_load(p, c0, b + 2, lane, ahead); // in flight during the walk
+        // this block's bytes to its lanes, the next block's masks
+        const uint64_t Wnext = tok_rows_mask(p, c0, b + 1, lane, nxt, smask, &cur, b, rows_lds);
         const TokBlock blk = tok_block(p, W, Wnext, a0 + 64u * b, st);
-        const uint8_t *mine = rows_lds + (b & 1u) * 64 * TOK_ROW_PITCH + lane * TOK_ROW_PITCH;
-        uint64_t ev = blk.keep | blk.closes; // in text order
-        while (ev) {
-            const uint32_t i = (uint32_t) __ffsll((unsigned long long) ev) - 1u;
-            ev &= ev - 1;
-            if ((blk.keep >> i) & 1ull) {
-                if ((blk.starts >> i) & 1ull) offs.put((uint32_t) (sink.v - back));
-                sink.put(mine[i]);
+        // A word carried into the block may end right at its first byte; every other end
+        // of a word follows a run of kept bytes of this block.  So: that one first, then
+        // run by run (a word that crosses a block boundary is two runs), each with the
+        // end of its word if it is here -- the same steps in every lane.
+        if (blk.closes & 1ull) {
+            sink.append(tail0, 8); // NUL + value (src/serializer.h:63-83, :157-168)
+            sink.append(tail1, 1);
+        }
+        uint64_t runs = blk.keep & ~(blk.keep << 1);
+        while (runs) {
+            const uint32_t i = (uint32_t) __ffsll((unsigned long long) runs) - 1u;
+            runs &= runs - 1;
+            if ((blk.starts >> i) & 1ull) offs.put((uint32_t) (sink.v - back));
+            const uint64_t rest = ~(blk.keep >> i);
+            const uint32_t len = rest ? (uint32_t) __ffsll((unsigned long long) rest) - 1u : 64u - i;
+            const uint64_t x = tok_row_get8(mine, i);
+            sink.append(len < 8 ? x & ((1ull << (8 * len)) - 1ull) : x, min(8u, len));
+            for (uint32_t j = 8; j < len; j += 8) { // rare: words of more than 8 bytes
+                const uint32_t k = min(8u, len - j);
+                const uint64_t y = tok_row_get8(mine, i + j);
+                sink.append(k < 8 ? y & ((1ull << (8 * k)) - 1ull) : y, k);
             }
-            else { // the word is complete: its NUL, then the value (src/serializer.h:63-83, :157-168)
-                sink.put(0);
-#pragma unroll
-                for (int k = 0; k < 8; k++) sink.put((uint8_t) (p.value >> (8 * k)));
+            if (i + len < 64 && ((blk.closes >> (i + len)) & 1ull)) {
+                sink.append(tail0, 8);
+                sink.append(tail1, 1);
             }
         }
         W = Wnext;
+        cur = nxt;
+        nxt = ahead;
     }
     sink.finish();
     offs.finish();
