@@ -250,6 +250,42 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes,
                         uint32_t *d_rec_off, uint64_t rec_off_capacity,
                         uint64_t *n_records, uint64_t *n_bytes, void *stream);
 
+/* ---- reduce side: KV -> KMV (group by key) ----------------------------------
+ * What the reduce phase starts with in the reference: KMVContainer::convert
+ * (src/kmvcontainer.h:74-150) looks every record's key up in a hash table whose
+ * entries keep the order of first insertion (src/hashbucket.h:185-290,
+ * :301-342), gives the unique keys consecutive slices of value buffers in that
+ * order and appends every record's value to its key's slice in stream order.
+ * The reduce callback then sees each unique key once, in the order of first
+ * occurrence, with its values in stream order (src/mimircontext.h:397-417).
+ * This call computes that grouping for a device-resident KV stream:
+ *
+ *   d_records / d_rec_off / n_records   as for mgs_pack_device (d_rec_off NULL
+ *                       for fixed-width records); n_records <= 2^30
+ *   d_group_first       out, device [group_capacity]: the index of the first
+ *                       record with the g-th unique key (the key is that
+ *                       record's key)
+ *   d_group_start       out, device [group_capacity + 1]: the number of records
+ *                       in groups before g; d_group_start[n_groups] = n_records
+ *   d_values            out, device [n_records * value bytes]: the values,
+ *                       grouped: group g's are entries d_group_start[g] ..
+ *                       d_group_start[g+1]-1, in stream order
+ *   page_bytes / cuts   the groups at which a new value buffer begins: a
+ *                       buffer is closed with the group that takes it to
+ *                       page_bytes or beyond (DATA_PAGE_SIZE, 64 MiB, in the
+ *                       reference, :105)
+ *
+ * Layouts: any key; the value fixed-width or absent (with string values the
+ * reference sizes the slices with a stale length, :84-94, so there is no
+ * defined result to match).  MGS_ERR_ARG when there are more groups than
+ * group_capacity or more cuts than max_cuts.  Blocking.  The stable sort of
+ * (group, record) pairs inside is rocPRIM's radix sort. */
+int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
+                     uint64_t n_records, uint32_t *d_group_first, uint32_t *d_group_start,
+                     uint64_t group_capacity, void *d_values, int64_t page_bytes,
+                     uint64_t *n_groups, uint64_t *cuts, int max_cuts, int *n_cuts,
+                     void *stream);
+
 /* ---- host-staged front end: what a Writable::write() shim calls -----------
  * The reference serialises every pair into the send buffer inside write()
  * (src/collectiveshuffler.h:143-146) because the caller's pointers die when

@@ -105,6 +105,9 @@ SYMBOLS = {
                                     C.c_int64, C.c_int64, C.POINTER(C.c_uint64),
                                     C.POINTER(PageCut), C.c_int,
                                     C.POINTER(C.c_int), _VP]),
+    "mgs_group_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, _VP, C.c_uint64, _VP,
+                                   C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                   C.c_int, C.POINTER(C.c_int), _VP]),
     "mgs_tokenize_device": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, C.c_uint64,
                                       _VP, C.c_uint64, C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64), _VP]),

@@ -19,6 +19,7 @@
 #include "mgs_onesweepv.h"
 #include "mgs_unpack.h"
 #include "mgs_tokenize.h"
+#include "mgs_group.h"
 
 using namespace mgs;
 
@@ -131,6 +132,8 @@ struct mgs_handle {
     size_t status_bytes = 0, agg16_bytes = 0;
     uint8_t *d_unp = nullptr;   // receive-side scratch (chunk and piece tables, cuts, result)
     size_t unp_bytes = 0;
+    uint8_t *d_grp = nullptr;   // reduce-side scratch (tables, sort buffers)
+    size_t grp_bytes = 0;
     uint64_t *h_unp = nullptr;  // pinned: result + cuts
     bool pending_osv = false; // the byte-granular one-sweep path was enqueued (may have fallen back)
     int ov_k = 4;             // records per worker lane for variable-width input, adapted call by call
@@ -231,6 +234,7 @@ void mgs_destroy(mgs_handle *h)
         if (h->d_status) (void) hipFree(h->d_status);
         if (h->d_agg16) (void) hipFree(h->d_agg16);
         if (h->d_unp) (void) hipFree(h->d_unp);
+        if (h->d_grp) (void) hipFree(h->d_grp);
         if (h->h_unp) (void) hipHostFree(h->h_unp);
         if (h->h_head) (void) hipHostFree(h->h_head);
         if (h->h_ctrl) (void) hipHostFree(h->h_ctrl);
@@ -889,6 +893,161 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint
     }
     *n_records = h->h_unp[0];
     *n_bytes = h->h_unp[1];
+    return MGS_OK;
+}
+
+// ---- reduce side: KV -> KMV -------------------------------------------------------
+int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_records,
+                     uint32_t *d_group_first, uint32_t *d_group_start, uint64_t group_capacity, void *d_values,
+                     int64_t page_bytes, uint64_t *n_groups, uint64_t *cuts, int max_cuts, int *n_cuts,
+                     void *stream_v)
+{
+    if (!h || !d_group_start || !n_groups || !n_cuts || (n_records && (!d_records || !d_group_first))
+        || (max_cuts > 0 && !cuts)) {
+        if (h) h->err = "mgs_group_device: NULL argument";
+        return MGS_ERR_ARG;
+    }
+    const mgs_layout &L = h->desc.layout;
+    if (L.val_kind == MGS_VAL_CSTR) {
+        h->err = "mgs_group_device: string values are not supported (fixed-width or no value)";
+        return MGS_ERR_ARG;
+    }
+    const uint32_t vbytes = L.val_kind == MGS_VAL_FIXED ? (uint32_t) L.val_bytes : 0u;
+    if (n_records > (1ull << 30) || page_bytes <= 0 || max_cuts < 0 || (vbytes && n_records && !d_values)
+        || (!h->fixed_len && n_records && !d_rec_off)) {
+        h->err = "mgs_group_device: at most 2^30 records, page_bytes > 0, d_values and (for variable width) "
+                 "d_rec_off required";
+        return MGS_ERR_ARG;
+    }
+    DeviceGuard g(h->desc.device);
+    if (!g.ok) {
+        h->err = "mgs_group_device: hipSetDevice failed";
+        return MGS_ERR_HIP;
+    }
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
+    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
+    *n_groups = 0;
+    *n_cuts = 0;
+    if (n_records == 0) {
+        MGS_HIP(h, hipMemsetAsync(d_group_start, 0, sizeof(uint32_t), stream));
+        MGS_HIP(h, hipStreamSynchronize(stream));
+        return MGS_OK;
+    }
+
+    GrpParams p;
+    memset(&p, 0, sizeof(p));
+    p.blob = static_cast<const uint8_t *>(d_records);
+    p.rec_off = h->fixed_len ? nullptr : d_rec_off;
+    p.fixed_len = h->fixed_len;
+    p.n = (uint32_t) n_records;
+    p.lay = L;
+    p.vbytes = vbytes;
+    uint32_t log_slots = 10;
+    while ((1ull << log_slots) < 2 * n_records) log_slots++;
+    const size_t slots = (size_t) 1 << log_slots;
+    p.slot_mask = (uint32_t) (slots - 1);
+    p.slot_shift = 32 - log_slots;
+    p.ntiles = (uint32_t) ((n_records + GRP_TILE - 1) / GRP_TILE);
+    p.group_first = d_group_first;
+    p.group_start = d_group_start;
+    p.group_cap = group_capacity;
+    p.values = static_cast<uint8_t *>(d_values);
+    p.page_bytes = page_bytes;
+    p.max_cuts = kUnpMaxCuts;
+    p.ctrl = h->d_ctrl;
+
+    size_t sort_bytes = 0;
+    {
+        const hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr,
+                                                       rocprim::counting_iterator<uint32_t>(0), (uint32_t *) nullptr,
+                                                       (size_t) n_records, 0u, 32u, stream);
+        if (e != hipSuccess) {
+            h->err = fmt("rocprim::radix_sort_pairs (size query) failed: %s", hipGetErrorString(e));
+            return MGS_ERR_HIP;
+        }
+    }
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t need = up((2 + kUnpMaxCuts) * sizeof(uint64_t)) + 2 * up(slots * sizeof(uint32_t))
+                        + 3 * up((size_t) n_records * sizeof(uint32_t)) + up(((size_t) p.ntiles + 1) * sizeof(uint32_t))
+                        + up(sort_bytes);
+    if (h->pending) { // one call in flight per handle: the control block is shared
+        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    }
+    if (need > h->grp_bytes) {
+        if (h->d_grp) {
+            MGS_HIP(h, hipDeviceSynchronize());
+            MGS_HIP(h, hipFree(h->d_grp));
+            h->d_grp = nullptr;
+            h->grp_bytes = 0;
+        }
+        MGS_HIP(h, hipMalloc(&h->d_grp, need));
+        h->grp_bytes = need;
+    }
+    uint8_t *q = h->d_grp;
+    p.result = reinterpret_cast<uint64_t *>(q);
+    p.cuts = p.result + 2;                               q += up((2 + kUnpMaxCuts) * sizeof(uint64_t));
+    p.table = reinterpret_cast<uint32_t *>(q);           q += up(slots * sizeof(uint32_t));
+    p.rank_table = reinterpret_cast<uint32_t *>(q);      q += up(slots * sizeof(uint32_t));
+    p.slot_or_rank = reinterpret_cast<uint32_t *>(q);    q += up((size_t) n_records * sizeof(uint32_t));
+    p.sorted_rank = reinterpret_cast<uint32_t *>(q);     q += up((size_t) n_records * sizeof(uint32_t));
+    p.sorted_rec = reinterpret_cast<uint32_t *>(q);      q += up((size_t) n_records * sizeof(uint32_t));
+    p.tile_count = reinterpret_cast<uint32_t *>(q);      q += up(((size_t) p.ntiles + 1) * sizeof(uint32_t));
+    void *sort_tmp = q;
+
+    const unsigned wide = (unsigned) std::min<uint64_t>((n_records + GRP_THREADS - 1) / GRP_THREADS,
+                                                        (uint64_t) std::max(h->num_cus, 1) * 32);
+    MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
+    MGS_HIP(h, hipMemsetAsync(p.result, 0, 2 * sizeof(uint64_t), stream));
+    MGS_HIP(h, hipMemsetAsync(p.table, 0xFF, slots * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_grp_insert, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(k_grp_count, dim3(p.ntiles), dim3(GRP_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(k_grp_scan, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(k_grp_rank, dim3(p.ntiles), dim3(GRP_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(k_grp_keys, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
+    MGS_HIP(h, hipGetLastError());
+    // the sort needs only the bits the ranks use: fetch the number of groups
+    MGS_HIP(h, hipMemcpyAsync(h->h_unp, p.result, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipMemcpyAsync(&h->h_ctrl->head.error, &h->d_ctrl->head.error, sizeof(int32_t),
+                              hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipStreamSynchronize(stream));
+    const uint64_t G = h->h_unp[0];
+    int derr = h->h_ctrl->head.error;
+    if (derr == 0) {
+        unsigned bits = 1;
+        while (bits < 32 && (1ull << bits) < G) bits++;
+        const hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, (const uint32_t *) p.slot_or_rank, p.sorted_rank,
+                                                       rocprim::counting_iterator<uint32_t>(0), p.sorted_rec,
+                                                       (size_t) n_records, 0u, bits, stream);
+        if (e != hipSuccess) {
+            h->err = fmt("rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+            return MGS_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k_grp_emit, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
+        hipLaunchKernelGGL(k_grp_pages, dim3(1), dim3(64), 0, stream, p);
+        MGS_HIP(h, hipGetLastError());
+        MGS_HIP(h, hipMemcpyAsync(h->h_unp, p.result, (2 + kUnpMaxCuts) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        MGS_HIP(h, hipMemcpyAsync(&h->h_ctrl->head.error, &h->d_ctrl->head.error, sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, stream));
+        MGS_HIP(h, hipStreamSynchronize(stream));
+        derr = h->h_ctrl->head.error;
+    }
+    if (derr != 0) {
+        switch (derr) {
+        case MGS_ERR_MALFORMED: h->err = "a record does not match the layout"; break;
+        case MGS_ERR_ARG: h->err = fmt("mgs_group_device: %llu groups, room for %llu", (unsigned long long) G,
+                                       (unsigned long long) group_capacity); break;
+        default: h->err = fmt("device error %d", derr);
+        }
+        return derr;
+    }
+    *n_groups = G;
+    const uint64_t nc = h->h_unp[1];
+    if (nc > (uint64_t) max_cuts || nc > kUnpMaxCuts) {
+        h->err = fmt("mgs_group_device: %llu value-buffer cuts, room for %d", (unsigned long long) nc, max_cuts);
+        return MGS_ERR_ARG;
+    }
+    for (uint64_t k = 0; k < nc; k++) cuts[k] = h->h_unp[2 + k];
+    *n_cuts = (int) nc;
     return MGS_OK;
 }
 

@@ -1,0 +1,281 @@
+// Reduce side: KV -> KMV (group the records of a rank by key) on the device.
+//
+// What it replaces: KMVContainer::convert (src/kmvcontainer.h:74-150) reads
+// the KV container twice.  Pass 1 looks every key up in a chained hash table
+// (HashBucket::findEntry / insertEntry, src/hashbucket.h:108-126, :185-290: a
+// new key is appended to the table's entry buffers, so HashBucket::next,
+// :301-342, walks the unique keys in the order of their first occurrence) and
+// adds up the value bytes per key; the unique keys are then given consecutive
+// slices of value buffers in that order (:98-130: a buffer is closed with the
+// entry that takes it to DATA_PAGE_SIZE or beyond); pass 2 appends every
+// record's value to its key's slice, in stream order (:132-144).  The reduce
+// callback then sees the unique keys in first-occurrence order, each with its
+// values in stream order (src/mimircontext.h:397-417).
+//
+// So the result is a stable group-by with groups ordered by first occurrence:
+//   group_first[g]  index of the first record with the g-th unique key
+//   group_start[g]  number of records in groups before g (values are fixed
+//                   width: value j of the output belongs to record sorted[j])
+//   values          the records' values, grouped
+//   cuts            the groups at which a new value buffer begins
+//
+//   k_grp_insert  open-addressing table of record indices: a slot holds the
+//                 smallest index seen so far of the records with one key
+//                 (keys are compared in the stream itself); slot of every record
+//   k_grp_count / k_grp_scan / k_grp_rank
+//                 a record is a first occurrence iff its slot holds its own
+//                 index; prefix sum over those flags = the group's rank, left in
+//                 a second table by the first record
+//   k_grp_keys    rank of every record's group (the sort key)
+//   (library)     stable radix sort of (rank, record index) pairs on the bits
+//                 the ranks need (rocPRIM; the one library primitive here)
+//   k_grp_emit    values in sorted order; group boundaries
+//   k_grp_pages   value-buffer cuts, 64 probes per search step
+#ifndef MGS_GROUP_H
+#define MGS_GROUP_H
+
+#include <rocprim/rocprim.hpp>
+
+#include "mgs_generic.h"
+
+namespace mgs {
+
+constexpr uint32_t GRP_EMPTY = 0xFFFFFFFFu;
+constexpr int GRP_THREADS = 256, GRP_ITEMS = 8, GRP_TILE = GRP_THREADS * GRP_ITEMS;
+
+struct GrpParams {
+    const uint8_t *blob;
+    const uint32_t *rec_off; // record index -> byte offset, or NULL (fixed width)
+    uint32_t fixed_len;
+    uint32_t n;              // records
+    mgs_layout lay;
+    uint32_t vbytes;         // value bytes per record (0 = no value)
+    uint32_t *table;         // [slots] smallest record index of a key, or GRP_EMPTY
+    uint32_t *rank_table;    // [slots] rank of the key's group
+    uint32_t slot_mask, slot_shift;
+    uint32_t *slot_or_rank;  // [n] slot of record i, later the rank of its group
+    uint32_t *sorted_rank;   // [n]
+    uint32_t *sorted_rec;    // [n]
+    uint32_t *tile_count;    // [ntiles + 1] first occurrences per tile, then exclusive sums (+ total)
+    uint32_t ntiles;
+    uint32_t *group_first;   // out [groups]
+    uint32_t *group_start;   // out [groups + 1]
+    uint64_t group_cap;
+    uint8_t *values;         // out [n * vbytes]
+    int64_t page_bytes;
+    uint64_t *cuts;          // out [max_cuts]
+    uint32_t max_cuts;
+    uint64_t *result;        // [0] groups, [1] cuts
+    Ctrl *ctrl;
+};
+
+struct __attribute__((packed)) GrpU64 { unsigned long long v; };
+
+__device__ __forceinline__ uint64_t grp_offset(const GrpParams &p, uint64_t i)
+{
+    return p.rec_off ? (uint64_t) p.rec_off[i] : i * (uint64_t) p.fixed_len;
+}
+
+// Key of record i: first byte and length (false: the record does not match the layout).
+__device__ __forceinline__ bool grp_key(const GrpParams &p, uint32_t i, const uint8_t *&key, uint32_t &klen)
+{
+    const uint64_t o0 = grp_offset(p, i), o1 = grp_offset(p, (uint64_t) i + 1);
+    key = p.blob + o0;
+    if (o1 <= o0 || o1 - o0 > GEN_MAX_RECORD) return false;
+    return gen_key_len(p.lay, key, (uint32_t) (o1 - o0), klen);
+}
+
+__device__ __forceinline__ bool grp_same_key(const uint8_t *a, uint32_t alen, const uint8_t *b, uint32_t blen)
+{
+    if (alen != blen) return false;
+    uint32_t j = 0;
+    for (; j + 8 <= alen; j += 8)
+        if (reinterpret_cast<const GrpU64 *>(a + j)->v != reinterpret_cast<const GrpU64 *>(b + j)->v) return false;
+    for (; j < alen; j++)
+        if (a[j] != b[j]) return false;
+    return true;
+}
+
+// One thread per record.  The hash is the reference's (hashlittle over the key
+// bytes); the slot is taken from its high bits after a multiplication, because
+// all keys of a rank share hash % nranks (the reference divides by the number
+// of ranks for the same reason, src/hashbucket.h:111).
+__global__ __launch_bounds__(GRP_THREADS) void k_grp_insert(GrpParams p)
+{
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t i64 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i64 < p.n; i64 += stride) {
+        const uint32_t i = (uint32_t) i64;
+        const uint8_t *key;
+        uint32_t klen = 0;
+        if (!grp_key(p, i, key, klen)) {
+            raise_error(p.ctrl, MGS_ERR_MALFORMED);
+            p.slot_or_rank[i] = 0;
+            continue;
+        }
+        const uint32_t h = hashlittle_bytes(key, klen);
+        uint32_t s = (h * 0x9E3779B1u) >> p.slot_shift;
+        for (uint32_t probes = 0; probes <= p.slot_mask; probes++) { // the table is at most half full
+            uint32_t cur = __hip_atomic_load(p.table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == GRP_EMPTY) {
+                cur = atomicCAS(p.table + s, GRP_EMPTY, i);
+                if (cur == GRP_EMPTY) break; // this record opened the slot
+            }
+            const uint8_t *okey;
+            uint32_t oklen = 0;
+            if (cur == i || (grp_key(p, cur, okey, oklen) && grp_same_key(key, klen, okey, oklen))) {
+                if (i < cur) atomicMin(p.table + s, i); // the slot keeps the first occurrence
+                break;
+            }
+            s = (s + 1) & p.slot_mask;
+        }
+        p.slot_or_rank[i] = s;
+    }
+}
+
+// First occurrences per tile of GRP_TILE records.
+__global__ __launch_bounds__(GRP_THREADS) void k_grp_count(GrpParams p)
+{
+    __shared__ uint32_t wsum[GRP_THREADS / 64];
+    const uint64_t t0 = (uint64_t) blockIdx.x * GRP_TILE;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; k++) {
+        const uint64_t i = t0 + (uint64_t) k * GRP_THREADS + threadIdx.x;
+        if (i < p.n) c += p.table[p.slot_or_rank[i]] == (uint32_t) i;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(c, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int ww = 0; ww < GRP_THREADS / 64; ww++) tot += wsum[ww];
+        p.tile_count[blockIdx.x] = tot;
+    }
+}
+
+// One workgroup: exclusive sums of the tile counts in place, total at [ntiles].
+__global__ __launch_bounds__(1024) void k_grp_scan(GrpParams p)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < p.ntiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < p.ntiles ? p.tile_count[t] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(v, lane);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int ww = 0; ww < w; ww++) before += wsum[ww];
+        if (t < p.ntiles) p.tile_count[t] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.tile_count[p.ntiles] = carry;
+        p.result[0] = carry;
+        if ((uint64_t) carry > p.group_cap) raise_error(p.ctrl, MGS_ERR_ARG);
+    }
+}
+
+// Rank of every first occurrence, left in rank_table[slot].  Records are taken
+// in index order inside a tile: thread t owns GRP_ITEMS consecutive records.
+__global__ __launch_bounds__(GRP_THREADS) void k_grp_rank(GrpParams p)
+{
+    __shared__ uint32_t wsum[GRP_THREADS / 64];
+    const uint64_t t0 = (uint64_t) blockIdx.x * GRP_TILE + (uint64_t) threadIdx.x * GRP_ITEMS;
+    uint32_t slot[GRP_ITEMS];
+    bool first[GRP_ITEMS];
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; k++) {
+        const uint64_t i = t0 + k;
+        slot[k] = i < p.n ? p.slot_or_rank[i] : 0u;
+        first[k] = i < p.n && p.table[slot[k]] == (uint32_t) i;
+        c += first[k];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(c, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t r = p.tile_count[blockIdx.x] + incl - c;
+    for (int ww = 0; ww < w; ww++) r += wsum[ww];
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; k++) {
+        if (first[k]) p.rank_table[slot[k]] = r++;
+    }
+}
+
+__global__ __launch_bounds__(GRP_THREADS) void k_grp_keys(GrpParams p)
+{
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride)
+        p.slot_or_rank[i] = p.rank_table[p.slot_or_rank[i]];
+}
+
+// One thread per sorted position: the record's value, and the group's entry
+// where a group begins.
+__global__ __launch_bounds__(GRP_THREADS) void k_grp_emit(GrpParams p)
+{
+    if (p.ctrl->head.error != 0) return;
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += stride) {
+        const uint32_t g = p.sorted_rank[j], i = p.sorted_rec[j];
+        if (j == 0 || p.sorted_rank[j - 1] != g) {
+            p.group_first[g] = i;
+            p.group_start[g] = (uint32_t) j;
+        }
+        if (p.vbytes) {
+            const uint8_t *src = p.blob + grp_offset(p, (uint64_t) i + 1) - p.vbytes; // the value ends the record
+            uint8_t *dst = p.values + j * p.vbytes;
+            uint32_t b = 0;
+            for (; b + 8 <= p.vbytes; b += 8)
+                reinterpret_cast<GrpU64 *>(dst + b)->v = reinterpret_cast<const GrpU64 *>(src + b)->v;
+            for (; b < p.vbytes; b++) dst[b] = src[b];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.group_start[p.tile_count[p.ntiles]] = p.n;
+}
+
+// src/kmvcontainer.h:98-119: groups are added to a value buffer until its bytes
+// reach page_bytes; the next group opens a new buffer.  One wave; the last
+// group of a buffer is found by a search that probes 64 places at a time.
+__global__ __launch_bounds__(64) void k_grp_pages(GrpParams p)
+{
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    if (p.ctrl->head.error != 0 || p.vbytes == 0) { // groups without value bytes never fill a buffer
+        if (lane == 0) p.result[1] = 0;
+        return;
+    }
+    const uint64_t G = p.result[0];
+    uint64_t g0 = 0, ncuts = 0;
+    while (g0 < G) {
+        // smallest e in (g0, G] with (group_start[e] - group_start[g0]) * vbytes >= page_bytes
+        const uint64_t base = p.group_start[g0];
+        if (((uint64_t) p.group_start[G] - base) * p.vbytes < (uint64_t) p.page_bytes) break;
+        uint64_t lo = g0 + 1, hi = G; // the answer is in [lo, hi]
+        while (lo < hi) {
+            const uint64_t step = (hi - lo + 63) / 64;
+            const uint64_t probe = min(hi, lo + (uint64_t) lane * step);
+            const bool full = ((uint64_t) p.group_start[probe] - base) * p.vbytes >= (uint64_t) p.page_bytes;
+            const uint64_t k = (uint64_t) __popcll(~__ballot(full)); // the sizes ascend: the first k probes are not full
+            // probe k is the first full one (k >= 1 unless lo itself is full)
+            const uint64_t nhi = min(hi, lo + k * step);
+            lo = k ? min(hi, lo + (k - 1) * step + 1) : lo;
+            hi = nhi;
+        }
+        if (lo >= G) break; // the buffer ends with the last group
+        if (ncuts < p.max_cuts && lane == 0) p.cuts[ncuts] = lo; // group `lo` opens the next buffer
+        ncuts++;
+        g0 = lo;
+    }
+    if (lane == 0) p.result[1] = ncuts;
+}
+
+} // namespace mgs
+#endif

@@ -165,6 +165,29 @@ def unpack_stream(packer, stream, nbytes, page_bytes=64 << 20, first_page_fill=0
                                    for i in range(ncuts.value)]
 
 
+def group_records(packer, records, n, rec_off=None, page_bytes=64 << 20, max_cuts=1024,
+                  group_capacity=None):
+    """KV -> KMV on the device (KMVContainer::convert): unique keys in the order of
+    first occurrence, values grouped in stream order.  Returns (group_first int32
+    tensor [G], group_start int32 tensor [G+1], values uint8 tensor, cuts list)."""
+    lay = packer.layout
+    vb = lay.val_bytes if lay.val_kind == capi.VAL_FIXED else 0
+    cap = n if group_capacity is None else group_capacity
+    first = torch.empty(max(cap, 1), dtype=torch.int32, device=records.device)
+    start = torch.empty(cap + 1, dtype=torch.int32, device=records.device)
+    values = torch.empty(max(n * vb, 1), dtype=torch.uint8, device=records.device)
+    G, nc = C.c_uint64(), C.c_int()
+    cuts = (C.c_uint64 * max(max_cuts, 1))()
+    s = torch.cuda.current_stream(packer.device).cuda_stream
+    if not s:  # see DevicePacker._args
+        torch.cuda.current_stream(packer.device).synchronize()
+    packer._check(packer.lib.mgs_group_device(
+        packer.h, _ptr(records), _ptr(rec_off), n, _ptr(first), _ptr(start), cap, _ptr(values),
+        page_bytes, C.byref(G), cuts, max_cuts, C.byref(nc), C.c_void_p(s)))
+    g = int(G.value)
+    return first[:g], start[:g + 1], values[:n * vb], [int(cuts[i]) for i in range(nc.value)]
+
+
 def tokenize_text(packer, text, nbytes, value=1, records=None, rec_off=None):
     """wordcount's map on the device: a device-resident text (uint8 tensor, whole
     lines) -> (records uint8 tensor, rec_off int32 tensor, n_records, n_bytes), the

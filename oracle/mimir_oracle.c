@@ -5,6 +5,7 @@
  */
 #include "mimir_oracle.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 /* ---- lookup3 hashlittle -------------------------------------------------
@@ -328,4 +329,91 @@ int64_t mo_tokenize(const uint8_t *text, int64_t nbytes, uint64_t value,
     }
     rec_off_out[nrec] = (uint64_t) opos;
     return nrec;
+}
+
+int64_t mo_kmv_convert(const mo_layout *lay, const uint8_t *blob,
+                       const uint64_t *rec_off, int64_t fixed_len, uint64_t n,
+                       uint32_t hashscale, int64_t page_bytes,
+                       uint32_t *group_first, uint64_t *group_start,
+                       uint8_t *values_out, uint64_t *cut_group_out,
+                       int64_t max_cuts, int64_t *n_cuts)
+{
+    if (lay->val_kind == MO_VAL_CSTR) return -1;
+    const int64_t vbytes = lay->val_kind == MO_VAL_FIXED ? lay->val_bytes : 0;
+    const uint32_t nbucket = 1024 * 1024; /* BUCKET_COUNT, src/config.cpp:15 */
+    if (hashscale == 0) hashscale = 1;
+    /* entries in insertion order; chains through `next` with insertion at the head
+     * (src/hashbucket.h:279-287) */
+    typedef struct { uint64_t off; int64_t klen; int64_t valbytes; int64_t fill; int64_t next; } entry;
+    int64_t *bucket = (int64_t *) malloc(sizeof(int64_t) * nbucket);
+    entry *ent = (entry *) malloc(sizeof(entry) * (n ? n : 1));
+    int64_t *group_of = (int64_t *) malloc(sizeof(int64_t) * (n ? n : 1));
+    int64_t G = 0, rc = -1;
+    if (!bucket || !ent || !group_of) goto done;
+    for (uint32_t b = 0; b < nbucket; b++) bucket[b] = -1;
+    for (uint64_t i = 0; i < n; i++) { /* pass 1, :83-96 */
+        uint64_t off;
+        int64_t len;
+        rec_span(rec_off, fixed_len, i, &off, &len);
+        const int64_t klen = mo_key_len(lay, blob + off, len);
+        if (klen < 0 || klen + vbytes != len) goto done;
+        const uint32_t ib = (mo_hashlittle(blob + off, (size_t) klen, 0) / hashscale) % nbucket;
+        int64_t e = bucket[ib];
+        while (e >= 0 && !(ent[e].klen == klen && memcmp(blob + ent[e].off, blob + off, (size_t) klen) == 0))
+            e = ent[e].next;
+        if (e < 0) {
+            e = G++;
+            ent[e].off = off;
+            ent[e].klen = klen;
+            ent[e].valbytes = vbytes;
+            ent[e].next = bucket[ib];
+            bucket[ib] = e;
+            group_first[e] = (uint32_t) i;
+        }
+        else {
+            ent[e].valbytes += vbytes;
+        }
+        group_of[i] = e;
+    }
+    { /* slices in entry order, :98-130 */
+        int64_t totalsize = 0, pos = 0, nc = 0;
+        for (int64_t e = 0; e < G; e++) {
+            group_start[e] = (uint64_t) (vbytes ? pos / vbytes : 0);
+            ent[e].fill = pos;
+            pos += ent[e].valbytes;
+            totalsize += ent[e].valbytes;
+            if (totalsize >= page_bytes && e + 1 < G) { /* this buffer is closed; the next entry opens one */
+                if (nc >= max_cuts) goto done;
+                cut_group_out[nc++] = (uint64_t) (e + 1);
+                totalsize = 0;
+            }
+        }
+        *n_cuts = nc;
+    }
+    if (vbytes == 0) { /* no value bytes: count the records per group instead */
+        uint64_t *cnt = (uint64_t *) calloc((size_t) (G ? G : 1), sizeof(uint64_t));
+        if (!cnt) goto done;
+        for (uint64_t i = 0; i < n; i++) cnt[group_of[i]]++;
+        uint64_t acc = 0;
+        for (int64_t e = 0; e < G; e++) {
+            group_start[e] = acc;
+            acc += cnt[e];
+        }
+        free(cnt);
+    }
+    group_start[G] = n;
+    for (uint64_t i = 0; i < n && vbytes; i++) { /* pass 2, :132-144 */
+        uint64_t off;
+        int64_t len;
+        rec_span(rec_off, fixed_len, i, &off, &len);
+        entry *e = &ent[group_of[i]];
+        memcpy(values_out + e->fill, blob + off + len - vbytes, (size_t) vbytes);
+        e->fill += vbytes;
+    }
+    rc = G;
+done:
+    free(bucket);
+    free(ent);
+    free(group_of);
+    return rc;
 }

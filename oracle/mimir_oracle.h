@@ -143,6 +143,26 @@ int64_t mo_tokenize(const uint8_t *text, int64_t nbytes, uint64_t value,
                     uint8_t *out, int64_t out_cap, uint64_t *rec_off_out,
                     int64_t max_records);
 
+/* KV -> KMV: KMVContainer::convert, src/kmvcontainer.h:74-150, over the
+ * records blob/rec_off (or fixed_len) as the KV container would hand them out.
+ * Pass 1 (:83-96): every key is looked up in a chained hash table, bucket
+ * (hashlittle(key) / hashscale) % nbucket (src/hashbucket.h:111); a new key is
+ * appended to the entry list (:263-287), which HashBucket::next walks in that
+ * order (:301-342).  Then the unique keys get consecutive slices of value
+ * buffers in that order; a buffer is closed with the entry that takes it to
+ * page_bytes or beyond (:98-119).  Pass 2 (:132-144) appends every record's
+ * value to its key's slice.  Values must be fixed-width or absent.
+ * Out: group_first[g] = index of the first record with the g-th unique key,
+ * group_start[0..G] = records in groups before g, values_out = the values
+ * grouped, cut_group_out = every group that opens a new value buffer.
+ * Returns G, or -1 (bad record, string values, too many cuts). */
+int64_t mo_kmv_convert(const mo_layout *lay, const uint8_t *blob,
+                       const uint64_t *rec_off, int64_t fixed_len, uint64_t n,
+                       uint32_t hashscale, int64_t page_bytes,
+                       uint32_t *group_first, uint64_t *group_start,
+                       uint8_t *values_out, uint64_t *cut_group_out,
+                       int64_t max_cuts, int64_t *n_cuts);
+
 #ifdef __cplusplus
 }
 #endif

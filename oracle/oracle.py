@@ -86,10 +86,34 @@ class Oracle:
         L.mo_page_cuts.restype = C.c_int64
         L.mo_page_cuts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_int64]
+        L.mo_kmv_convert.restype = C.c_int64
+        L.mo_kmv_convert.argtypes = [C.POINTER(Layout), C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.mo_tokenize.restype = C.c_int64
         L.mo_tokenize.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_int64]
         self.L = L
+
+    def kmv_convert(self, lay, blob, rec_off, n, hashscale=1, page_bytes=64 << 20):
+        """KMVContainer::convert: (group_first u32[G], group_start u64[G+1],
+        values uint8, cut groups u64[])."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = self._offs(rec_off)
+        vb = lay.val_bytes if lay.val_kind == VAL_FIXED else 0
+        first = np.zeros(max(n, 1), dtype=np.uint32)
+        start = np.zeros(n + 1, dtype=np.uint64)
+        values = np.zeros(max(n * vb, 1), dtype=np.uint8)
+        cuts = np.zeros(4096, dtype=np.uint64)
+        nc = C.c_int64()
+        G = self.L.mo_kmv_convert(C.byref(lay), blob.ctypes.data,
+                                  offs.ctypes.data if offs is not None else None,
+                                  lay.fixed_len() if offs is None else 0, n, hashscale, page_bytes,
+                                  first.ctypes.data, start.ctypes.data, values.ctypes.data,
+                                  cuts.ctypes.data, len(cuts), C.byref(nc))
+        if G < 0:
+            raise ValueError("oracle: kmv_convert failed")
+        return first[:G], start[:G + 1], values[:n * vb], cuts[:nc.value]
 
     def tokenize(self, text, value=1):
         """wordcount's map over a text: (records uint8, rec_off uint64[n+1])."""
