@@ -969,6 +969,7 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t need = up((2 + kUnpMaxCuts) * sizeof(uint64_t)) + 2 * up(slots * sizeof(uint32_t))
                         + 3 * up((size_t) n_records * sizeof(uint32_t)) + up(((size_t) p.ntiles + 1) * sizeof(uint32_t))
+                        + up((size_t) p.ntiles * (GRP_TILE / 64) * sizeof(uint64_t))
                         + up(sort_bytes);
     if (h->pending) { // one call in flight per handle: the control block is shared
         MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
@@ -992,6 +993,7 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
     p.sorted_rank = reinterpret_cast<uint32_t *>(q);     q += up((size_t) n_records * sizeof(uint32_t));
     p.sorted_rec = reinterpret_cast<uint32_t *>(q);      q += up((size_t) n_records * sizeof(uint32_t));
     p.tile_count = reinterpret_cast<uint32_t *>(q);      q += up(((size_t) p.ntiles + 1) * sizeof(uint32_t));
+    p.first_bits = reinterpret_cast<uint64_t *>(q);      q += up((size_t) p.ntiles * (GRP_TILE / 64) * sizeof(uint64_t));
     void *sort_tmp = q;
 
     const unsigned wide = (unsigned) std::min<uint64_t>((n_records + GRP_THREADS - 1) / GRP_THREADS,

@@ -57,6 +57,7 @@ struct GrpParams {
     uint32_t *sorted_rank;   // [n]
     uint32_t *sorted_rec;    // [n]
     uint32_t *tile_count;    // [ntiles + 1] first occurrences per tile, then exclusive sums (+ total)
+    uint64_t *first_bits;    // [ntiles * GRP_TILE / 64] bit i: record i is the first with its key
     uint32_t ntiles;
     uint32_t *group_first;   // out [groups]
     uint32_t *group_start;   // out [groups + 1]
@@ -132,20 +133,23 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_insert(GrpParams p)
     }
 }
 
-// First occurrences per tile of GRP_TILE records.
+// First occurrences per tile of GRP_TILE records: their number, and one bit per
+// record (wave `w` of the tile takes records k * GRP_THREADS + 64 w + lane).
 __global__ __launch_bounds__(GRP_THREADS) void k_grp_count(GrpParams p)
 {
     __shared__ uint32_t wsum[GRP_THREADS / 64];
     const uint64_t t0 = (uint64_t) blockIdx.x * GRP_TILE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t c = 0;
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; k++) {
         const uint64_t i = t0 + (uint64_t) k * GRP_THREADS + threadIdx.x;
-        if (i < p.n) c += p.table[p.slot_or_rank[i]] == (uint32_t) i;
+        const bool first = i < p.n && p.table[p.slot_or_rank[i]] == (uint32_t) i;
+        const uint64_t bits = __ballot(first);
+        if (lane == 0) p.first_bits[(t0 + (uint64_t) k * GRP_THREADS) / 64 + w] = bits;
+        c += (uint32_t) __popcll(bits);
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t incl = wave_incl_scan_u32(c, lane);
-    if (lane == 63) wsum[w] = incl;
+    if (lane == 0) wsum[w] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
@@ -182,31 +186,35 @@ __global__ __launch_bounds__(1024) void k_grp_scan(GrpParams p)
     }
 }
 
-// Rank of every first occurrence, left in rank_table[slot].  Records are taken
-// in index order inside a tile: thread t owns GRP_ITEMS consecutive records.
+// Rank of every first occurrence, left in rank_table[slot]: the tile's base plus
+// the first occurrences before it in the tile, counted on the tile's bits.
 __global__ __launch_bounds__(GRP_THREADS) void k_grp_rank(GrpParams p)
 {
-    __shared__ uint32_t wsum[GRP_THREADS / 64];
-    const uint64_t t0 = (uint64_t) blockIdx.x * GRP_TILE + (uint64_t) threadIdx.x * GRP_ITEMS;
-    uint32_t slot[GRP_ITEMS];
-    bool first[GRP_ITEMS];
-    uint32_t c = 0;
-#pragma unroll
-    for (int k = 0; k < GRP_ITEMS; k++) {
-        const uint64_t i = t0 + k;
-        slot[k] = i < p.n ? p.slot_or_rank[i] : 0u;
-        first[k] = i < p.n && p.table[slot[k]] == (uint32_t) i;
-        c += first[k];
-    }
+    constexpr int WORDS = GRP_TILE / 64;
+    static_assert(WORDS <= 64, "one wave scans the tile's words");
+    __shared__ uint64_t word[WORDS];
+    __shared__ uint32_t before[WORDS];
+    const uint64_t t0 = (uint64_t) blockIdx.x * GRP_TILE;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t incl = wave_incl_scan_u32(c, lane);
-    if (lane == 63) wsum[w] = incl;
+    if (w == 0) {
+        const uint64_t bits = lane < WORDS ? p.first_bits[t0 / 64 + lane] : 0ull;
+        const uint32_t c = (uint32_t) __popcll(bits);
+        const uint32_t incl = wave_incl_scan_u32(c, lane);
+        if (lane < WORDS) {
+            word[lane] = bits;
+            before[lane] = incl - c;
+        }
+    }
     __syncthreads();
-    uint32_t r = p.tile_count[blockIdx.x] + incl - c;
-    for (int ww = 0; ww < w; ww++) r += wsum[ww];
+    const uint32_t base = p.tile_count[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; k++) {
-        if (first[k]) p.rank_table[slot[k]] = r++;
+        const int wi = k * (GRP_THREADS / 64) + w;
+        const uint64_t bits = word[wi];
+        if ((bits >> lane) & 1ull) {
+            const uint64_t i = t0 + (uint64_t) wi * 64 + lane;
+            p.rank_table[p.slot_or_rank[i]] = base + before[wi] + (uint32_t) __popcll(bits & ((1ull << lane) - 1ull));
+        }
     }
 }
 
