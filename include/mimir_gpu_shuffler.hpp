@@ -61,6 +61,29 @@ class Exchange {
     virtual void alltoall_int(const int *send, int *recv) = 0;
     virtual void alltoallv_bytes(const char *sendbuf, const int *scount, const int *sdispl,
                                  char *recvbuf, const int *rcount, const int *rdispl) = 0;
+    // Non-blocking forms for NBGpuShuffler (MPI_Ialltoall / MPI_Ialltoallv /
+    // MPI_Test / MPI_Wait; the counts and the payloads travel on two separate
+    // communicators in the reference, src/nbcollectiveshuffler.h:68-69).  A
+    // request is an opaque pointer, NULL once complete.  The defaults complete
+    // at once through the blocking calls, which keeps the order of collective
+    // calls the same on every rank.
+    typedef void *Request;
+    virtual Request ialltoall_int(const int *send, int *recv)
+    {
+        alltoall_int(send, recv);
+        return NULL;
+    }
+    virtual Request ialltoallv_bytes(const char *sendbuf, const int *scount, const int *sdispl,
+                                     char *recvbuf, const int *rcount, const int *rdispl)
+    {
+        alltoallv_bytes(sendbuf, scount, sdispl, recvbuf, rcount, rdispl);
+        return NULL;
+    }
+    virtual bool test(Request &req) { return req == NULL; } // true: complete, req released and NULL
+    virtual void wait(Request &req)
+    {
+        while (!test(req)) {}
+    }
     virtual void abort(int code) { std::exit(code); }
 };
 
@@ -233,15 +256,24 @@ class GpuShuffler : public Writable<KeyType, ValType> {
             int drained = 0;
             if (mgs_stager_pack(stager, &r, &local, &drained) != MGS_OK) fail(mgs_stager_last_error(stager));
             kvcount += r.packed_records;
-            if (r.local_bytes > 0) // out->write at emit time, :135-141
+            if (r.local_bytes > 0) { // out->write at emit time, :135-141
+                begin_source(shuffle_rank);
                 deliver(const_cast<char *>(static_cast<const char *>(local)), r.local_bytes);
+            }
+            progress();
             if (drained) break;
             exchange_kv();
         }
     }
 
+    // Called before the records of one source rank are handed to `out` (the own
+    // rank for records that never leave it).  For tests and tracing.
+    virtual void begin_source(int src) { (void) src; }
+    // Called after every pack; the non-blocking shuffler pushes its exchanges here.
+    virtual void progress() {}
+
     // src/collectiveshuffler.h:587-674
-    void exchange_kv()
+    virtual void exchange_kv()
     {
         const void *image = NULL;
         const int64_t *send_offset = NULL;
@@ -266,13 +298,18 @@ class GpuShuffler : public Writable<KeyType, ValType> {
         }
         comm->alltoallv_bytes(static_cast<const char *>(image), send_count.data(), a2a_s_displs.data(),
                               recv_buffer.data(), recv_count.data(), a2a_r_displs.data());
-        if (recvcount > 0) deliver(recv_buffer.data(), recvcount); // save_data, :563-585
+        for (int i = 0; i < shuffle_size; i++) { // save_data, :563-585
+            if (recv_count[(size_t) i] > 0) {
+                begin_source(i);
+                deliver(recv_buffer.data() + a2a_r_displs[(size_t) i], recv_count[(size_t) i]);
+            }
+        }
         mgs_stager_round_done(stager);
         shuffle_times += 1;
     }
 
     // src/collectiveshuffler.h:528-561
-    void wait()
+    virtual void wait()
     {
         drain();
         while (sendcount() > 0 || shuffle_times == 0) exchange_kv();
@@ -360,6 +397,238 @@ class GpuShuffler : public Writable<KeyType, ValType> {
     std::vector<int> send_count, recv_count, a2a_s_displs, a2a_r_displs;
     typename ptr_store<KeyType>::type key_ptrs;
     typename ptr_store<ValType>::type val_ptrs;
+};
+
+// ---- the non-blocking shuffler -------------------------------------------------
+// NBCollectiveShuffler (src/nbcollectiveshuffler.h): the same partition image,
+// but 2..5 message buffers, so that the exchange of a full round is in flight
+// while the next round is packed.  Each exchange is a non-blocking all-to-all
+// of the counts (with the -1 vote) followed, in token order, by a non-blocking
+// all-to-all-v of the bytes (:222-387).  Records are packed on the device into
+// the stager's image as for GpuShuffler; when a round is full its partitions
+// move into the current message buffer and the image is free again.
+template <typename KeyType, typename ValType>
+class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
+    typedef GpuShuffler<KeyType, ValType> Base;
+
+  public:
+    enum { MIN_SBUF_COUNT = 2, MAX_SBUF_COUNT = 5 }; // src/config.cpp:20-21
+
+    NBGpuShuffler(Exchange *comm, Writable<KeyType, ValType> *out,
+                  int (*user_hash)(KeyType *key, ValType *val, int npartition), int keycount,
+                  int valcount, bool split_hint = false, void *h = NULL, int64_t comm_buf_size = 0,
+                  int device = 0)
+        : Base(comm, out, user_hash, keycount, valcount, split_hint, h, comm_buf_size, device)
+    {
+        cur_idx = 0;
+        a2a_token = a2av_token = 0;
+        pending_msg = 0;
+    }
+
+    virtual ~NBGpuShuffler()
+    {
+        for (size_t i = 0; i < msg.size(); i++) delete msg[i];
+    }
+
+    virtual int open() // :72-120
+    {
+        Base::open();
+        for (size_t i = 0; i < msg.size(); i++) delete msg[i];
+        msg.clear();
+        cur_idx = 0;
+        a2a_token = a2av_token = 0;
+        pending_msg = 0;
+        for (int i = 0; i < MIN_SBUF_COUNT; i++) insert_comm_buffer();
+        return true;
+    }
+
+    virtual void make_progress(bool issue_new = false) // :185-189
+    {
+        this->drain();
+        if (issue_new && pending_msg == 0) exchange_kv();
+        push_kv_exchange();
+    }
+
+    int get_buffer_count() const { return (int) msg.size(); }
+
+  protected:
+    enum State { ShuffleMsgStart, ShuffleMsgPending, ShuffleMsgComplete }; // :22-34
+
+    struct MsgBuf {
+        std::vector<char> send_buffer, recv_buffer;
+        std::vector<int> send_offset, recv_count, s_displs, r_displs;
+        uint64_t token;
+        State state;
+        bool counts_known;
+        Exchange::Request a2a_req, a2av_req;
+    };
+
+    void insert_comm_buffer() // :426-449
+    {
+        MsgBuf *m = new MsgBuf();
+        const size_t P = (size_t) this->shuffle_size;
+        m->send_buffer.resize((size_t) this->buf_size * P);
+        m->recv_buffer.resize((size_t) this->buf_size * P);
+        m->send_offset.assign(P, 0);
+        m->recv_count.assign(P, 0);
+        m->s_displs.assign(P, 0);
+        m->r_displs.assign(P, 0);
+        m->token = 0;
+        m->state = ShuffleMsgComplete;
+        m->counts_known = false;
+        m->a2a_req = m->a2av_req = NULL;
+        msg.push_back(m);
+    }
+
+    virtual void progress() { push_kv_exchange(); } // after every record in the reference, :179
+
+    // A round is full (or the stream has ended): its partitions leave the stager's image
+    // for the current message buffer and the exchange is started.
+    virtual void exchange_kv()
+    {
+        snapshot();
+        start_kv_exchange();
+    }
+
+    int64_t snapshot()
+    {
+        const void *image = NULL;
+        const int64_t *send_offset = NULL;
+        if (mgs_stager_send_image_host(this->stager, &image, &send_offset) != MGS_OK)
+            this->fail(mgs_stager_last_error(this->stager));
+        MsgBuf *m = msg[(size_t) cur_idx];
+        int64_t total = 0;
+        for (int i = 0; i < this->shuffle_size; i++) {
+            const int64_t so = send_offset[i];
+            if (so > 0)
+                memcpy(m->send_buffer.data() + (size_t) i * (size_t) this->buf_size,
+                       static_cast<const char *>(image) + (size_t) i * (size_t) this->buf_size, (size_t) so);
+            m->send_offset[(size_t) i] = (int) so;
+            total += so;
+        }
+        mgs_stager_round_done(this->stager);
+        return total;
+    }
+
+    void start_kv_exchange() // :222-277
+    {
+        MsgBuf *m = msg[(size_t) cur_idx];
+        const int P = this->shuffle_size;
+        if (this->done_flag)
+            for (int i = 0; i < P; i++) m->send_offset[(size_t) i] = -1;
+        this->shuffle_times += 1;
+        m->counts_known = false;
+        m->a2a_req = this->comm->ialltoall_int(m->send_offset.data(), m->recv_count.data());
+        m->state = ShuffleMsgStart;
+        m->token = a2a_token++;
+        pending_msg += 1;
+        push_kv_exchange();
+        // the next buffer to pack into: a complete one, else a new one, else wait for one
+        cur_idx = -1;
+        for (size_t i = 0; i < msg.size(); i++) {
+            if (msg[i]->state == ShuffleMsgComplete) {
+                cur_idx = (int) i;
+                break;
+            }
+        }
+        if (cur_idx == -1) {
+            if ((int) msg.size() < MAX_SBUF_COUNT) {
+                insert_comm_buffer();
+                cur_idx = (int) msg.size() - 1;
+            }
+            else {
+                cur_idx = 0;
+                for (;;) {
+                    push_kv_exchange();
+                    if (msg[(size_t) cur_idx]->state == ShuffleMsgComplete) break;
+                    cur_idx = (cur_idx + 1) % (int) msg.size();
+                }
+            }
+        }
+    }
+
+    void push_kv_exchange() // :279-387
+    {
+        const int P = this->shuffle_size;
+        for (size_t k = 0; k < msg.size(); k++) {
+            MsgBuf *m = msg[k];
+            if (m->state == ShuffleMsgComplete) continue;
+            if (m->state == ShuffleMsgStart) {
+                if (!m->counts_known && this->comm->test(m->a2a_req)) {
+                    this->done_count = 0;
+                    for (int i = 0; i < P; i++)
+                        if (m->recv_count[(size_t) i] == -1) this->done_count++;
+                    m->counts_known = true;
+                }
+                if (m->counts_known && this->done_count == P) { // everybody voted: nothing to move
+                    m->state = ShuffleMsgComplete;
+                    pending_msg -= 1;
+                    reset(m);
+                    continue;
+                }
+                if (m->counts_known && m->token == a2av_token && this->done_count < P) {
+                    int64_t recvcount = 0;
+                    for (int i = 0; i < P; i++) {
+                        if (m->send_offset[(size_t) i] == -1) m->send_offset[(size_t) i] = 0;
+                        if (m->recv_count[(size_t) i] == -1) m->recv_count[(size_t) i] = 0;
+                        m->s_displs[(size_t) i] = (int) (i * this->buf_size);
+                        m->r_displs[(size_t) i] = (int) recvcount;
+                        recvcount += m->recv_count[(size_t) i];
+                    }
+                    m->a2av_req = this->comm->ialltoallv_bytes(m->send_buffer.data(), m->send_offset.data(),
+                                                               m->s_displs.data(), m->recv_buffer.data(),
+                                                               m->recv_count.data(), m->r_displs.data());
+                    m->state = ShuffleMsgPending;
+                    a2av_token += 1;
+                }
+            }
+            if (m->state == ShuffleMsgPending && this->comm->test(m->a2av_req)) {
+                save_data(m);
+                reset(m);
+                m->state = ShuffleMsgComplete;
+                pending_msg -= 1;
+            }
+        }
+    }
+
+    void save_data(MsgBuf *m) // :400-424
+    {
+        for (int i = 0; i < this->shuffle_size; i++) {
+            if (m->recv_count[(size_t) i] > 0) {
+                this->begin_source(i);
+                this->deliver(m->recv_buffer.data() + m->r_displs[(size_t) i], m->recv_count[(size_t) i]);
+            }
+        }
+    }
+
+    void reset(MsgBuf *m)
+    {
+        m->token = 0;
+        m->counts_known = false;
+        for (int i = 0; i < this->shuffle_size; i++) m->send_offset[(size_t) i] = 0;
+    }
+
+    void wait_all() // :396-399
+    {
+        while (pending_msg > 0) push_kv_exchange();
+    }
+
+    virtual void wait() // :192-220
+    {
+        this->drain();
+        if (this->sendcount() > 0) exchange_kv();
+        wait_all();
+        this->done_flag = 1;
+        do {
+            start_kv_exchange();
+            wait_all();
+        } while (this->done_count < this->shuffle_size);
+    }
+
+    std::vector<MsgBuf *> msg;
+    int cur_idx;
+    uint64_t a2a_token, a2av_token;
+    int pending_msg;
 };
 
 } // namespace mimir_gpu

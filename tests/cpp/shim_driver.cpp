@@ -3,9 +3,12 @@
 // a GpuShuffler<K,V> the way a Mimir map callback does, with an in-process
 // all-to-all standing in for MPI.  Dumps what each rank's `out` received.
 //
-//   shim_driver <kind> <P> <comm_bytes> <stage_bytes> <indir> <outdir> [keycount]
-//   kind: u64 | words | oct | join
+//   shim_driver <kind> <P> <comm_bytes> <stage_bytes> <indir> <outdir> [keycount] [nb]
+//   kind: u64 | words | oct | join;  nb: NBGpuShuffler over non-blocking exchanges
 #include <pthread.h>
+
+#include <map>
+#include <mutex>
 
 #include <cstdio>
 #include <cstdlib>
@@ -23,12 +26,32 @@ struct Blob16 {
     char b[16];
 };
 
+// One non-blocking collective, matched across ranks by its sequence number:
+// every rank leaves what it sends (payloads are copied at post time, so the
+// sender's buffer is free at once); the operation is complete for a rank once
+// all ranks have posted.
+struct NbOp {
+    int arrived = 0, readers = 0;
+    std::vector<int> counts;             // P x P
+    std::vector<std::vector<char>> data; // P x P (payload operations)
+};
+
 struct Shared {
     int P;
     pthread_barrier_t bar;
     std::vector<int> counts;           // P x P
     std::vector<const char *> sendbuf; // per rank
     std::vector<const int *> scount, sdispl;
+    std::mutex mu;
+    std::map<uint64_t, NbOp> a2a, a2av;
+};
+
+struct NbReq {
+    bool payload;
+    uint64_t seq;
+    int *recv_counts;
+    char *recvbuf;
+    const int *rcount, *rdispl;
 };
 
 class ThreadExchange : public Exchange {
@@ -60,18 +83,69 @@ class ThreadExchange : public Exchange {
         }
         pthread_barrier_wait(&s->bar);
     }
+    Request ialltoall_int(const int *send, int *recv)
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        NbOp &op = s->a2a[a2a_seq];
+        if (op.counts.empty()) op.counts.assign((size_t)(s->P * s->P), 0);
+        for (int d = 0; d < s->P; d++) op.counts[(size_t)(r * s->P + d)] = send[d];
+        op.arrived++;
+        return new NbReq{false, a2a_seq++, recv, NULL, NULL, NULL};
+    }
+    Request ialltoallv_bytes(const char *sendbuf, const int *scount, const int *sdispl, char *recvbuf,
+                             const int *rcount, const int *rdispl)
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        NbOp &op = s->a2av[a2av_seq];
+        if (op.counts.empty()) {
+            op.counts.assign((size_t)(s->P * s->P), 0);
+            op.data.resize((size_t)(s->P * s->P));
+        }
+        for (int d = 0; d < s->P; d++) {
+            op.counts[(size_t)(r * s->P + d)] = scount[d];
+            op.data[(size_t)(r * s->P + d)].assign(sendbuf + sdispl[d], sendbuf + sdispl[d] + scount[d]);
+        }
+        op.arrived++;
+        return new NbReq{true, a2av_seq++, NULL, recvbuf, rcount, rdispl};
+    }
+    bool test(Request &req)
+    {
+        if (req == NULL) return true;
+        NbReq *q = static_cast<NbReq *>(req);
+        std::lock_guard<std::mutex> g(s->mu);
+        std::map<uint64_t, NbOp> &ops = q->payload ? s->a2av : s->a2a;
+        NbOp &op = ops[q->seq];
+        if (op.arrived < s->P) return false;
+        for (int src = 0; src < s->P; src++) {
+            const int c = op.counts[(size_t)(src * s->P + r)];
+            if (!q->payload) {
+                q->recv_counts[src] = c;
+                continue;
+            }
+            if (q->rcount[src] != c) {
+                fprintf(stderr, "count mismatch %d<-%d\n", r, src);
+                std::abort();
+            }
+            memcpy(q->recvbuf + q->rdispl[src], op.data[(size_t)(src * s->P + r)].data(), (size_t) c);
+        }
+        if (++op.readers == s->P) ops.erase(q->seq);
+        delete q;
+        req = NULL;
+        return true;
+    }
     void abort(int code) { std::_Exit(code); }
 
   private:
     Shared *s;
     int r;
+    uint64_t a2a_seq = 0, a2av_seq = 0;
 };
 
 // Sink: re-serialises every pair it is handed, so the dump is wire form again.
 template <typename K, typename V>
 class DumpSink : public Writable<K, V> {
   public:
-    DumpSink(int keycount, int valcount) : kc(keycount), vc(valcount), n(0) { off.push_back(0); }
+    DumpSink(int keycount, int valcount) : cur_src(-1), kc(keycount), vc(valcount), n(0) { off.push_back(0); }
     int open() { return true; }
     void close() {}
     int seek(DB_POS) { return false; }
@@ -86,11 +160,14 @@ class DumpSink : public Writable<K, V> {
         const char *vb = wire<V>::bytes(val, vc, tmp);
         if (vl) data.insert(data.end(), vb, vb + vl);
         off.push_back((uint64_t) data.size());
+        src.push_back(cur_src);
         n++;
         return true;
     }
     std::vector<char> data;
     std::vector<uint64_t> off;
+    std::vector<int32_t> src; // the rank every record came from
+    int cur_src;
 
   private:
     int kc, vc;
@@ -103,6 +180,19 @@ static std::vector<char> slurp(const std::string &p)
     return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
 
+// The shuffler under test, telling the sink whose records come next.
+template <typename Sh, typename K, typename V>
+class Tagged : public Sh {
+  public:
+    using Sh::Sh;
+    DumpSink<K, V> *sink = NULL;
+
+  protected:
+    void begin_source(int src) { sink->cur_src = src; }
+};
+
+static bool g_nb = false;
+
 template <typename K, typename V, typename Feed>
 static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const std::string &indir,
                      const std::string &outdir, int keycount, Feed feed)
@@ -113,7 +203,20 @@ static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const s
     const size_t n = offb.size() / 8 - 1;
     ThreadExchange ex(sh, r);
     DumpSink<K, V> sink(keycount, 1);
-    GpuShuffler<K, V> *c = new GpuShuffler<K, V>(&ex, &sink, NULL, keycount, 1, false, NULL, comm, 0);
+    GpuShuffler<K, V> *c;
+    NBGpuShuffler<K, V> *nb = NULL;
+    if (g_nb) {
+        Tagged<NBGpuShuffler<K, V>, K, V> *t =
+            new Tagged<NBGpuShuffler<K, V>, K, V>(&ex, &sink, NULL, keycount, 1, false, NULL, comm, 0);
+        t->sink = &sink;
+        c = nb = t;
+    }
+    else {
+        Tagged<GpuShuffler<K, V>, K, V> *t =
+            new Tagged<GpuShuffler<K, V>, K, V>(&ex, &sink, NULL, keycount, 1, false, NULL, comm, 0);
+        t->sink = &sink;
+        c = t;
+    }
     c->open();
     for (size_t i = 0; i < n; i++) feed(c, blob.data() + off[i], (int) (off[i + 1] - off[i]));
     c->close();
@@ -121,8 +224,11 @@ static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const s
         .write(sink.data.data(), (std::streamsize) sink.data.size());
     std::ofstream(outdir + "/rank" + std::to_string(r) + ".outoff", std::ios::binary)
         .write(reinterpret_cast<const char *>(sink.off.data()), (std::streamsize)(sink.off.size() * 8));
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".outsrc", std::ios::binary)
+        .write(reinterpret_cast<const char *>(sink.src.data()), (std::streamsize)(sink.src.size() * 4));
     std::ofstream(outdir + "/rank" + std::to_string(r) + ".txt")
-        << c->get_record_count() << " " << c->get_shuffle_times() << "\n";
+        << c->get_record_count() << " " << c->get_shuffle_times() << " " << (nb ? nb->get_buffer_count() : 1)
+        << "\n";
     delete c;
 }
 
@@ -137,6 +243,7 @@ int main(int argc, char **argv)
     const int64_t comm = atoll(argv[3]), stage = atoll(argv[4]);
     const std::string indir = argv[5], outdir = argv[6];
     const int keycount = argc > 7 ? atoi(argv[7]) : 1;
+    g_nb = argc > 8 && std::string(argv[8]) == "nb";
     setenv("MIMIR_GPU_STAGE_SIZE", std::to_string(stage).c_str(), 1);
     Shared sh;
     sh.P = P;
