@@ -12,9 +12,6 @@
 #include "mgs_common.h"
 #include "mgs_generic.h"
 #include "mgs_onesweep16.h"
-#include "mgs_onesweep16s.h"
-#include "mgs_onesweep16p.h"
-#include "mgs_onesweep16f.h"
 #include "mgs_onesweep16w.h"
 #include "mgs_onesweepv.h"
 #include "mgs_unpack.h"
@@ -72,12 +69,6 @@ struct OsVariant {
 #define MINW_(T, B) ((B * (T / 64) + 3) / 4)
 #define SAME7(k) {k, k, k, k, k, k, k}
 #define OSV(name, T, I, V, B) {name, T, I, B, T * I, false, SAME7((k_onesweep16<T, I, V, MINW_(T, B)>))}
-#define OSS(name, T, I, V, B) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, false, SAME7((k_onesweep16s<T, I, V, MINW_(T, B)>))}
-#define OSP(name, T, I, V, B, L) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, false, SAME7((k_onesweep16p<T, I, V, MINW_(T, B), L>))}
-#define OSF(name, T, I, V, B, L) \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, ((V) & OSV_WINDOW) != 0, SAME7((k_onesweep16f<T, I, V, MINW_(T, B), L>))}
 #define OSQ(name, T, I, V, B, L)                                                                    \
     {name, T, I, B, (T / 64 - 1) * 64 * I, true,                                                    \
      {nullptr, k_onesweep16q<T, I, V, MINW_(T, B), L, 1>, k_onesweep16q<T, I, V, MINW_(T, B), L, 2>, \
@@ -95,17 +86,6 @@ static const OsVariant kOsVariants[] = {
     OSV("t512x8", 512, 8, 0, 2),                            // 8: LDS image, every wave works, wave 0 walks
     OSV("t512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
     OSV("t512x8-stats", 512, 8, OSV_STATS, 2),              // 10
-    OSS("s512x8", 512, 8, 0, 2),                            // scan wave, one loop
-    OSS("s512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),     // 12
-    OSS("s512x8-stats", 512, 8, OSV_STATS, 2),
-    OSP("p512x8-w16", 512, 8, 0, 2, 16),                    // 14: scan wave, split loops, 128-tile walk
-    OSP("p512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 16),
-    OSP("p512x8-w16-stats", 512, 8, OSV_STATS, 2, 16),      // 16
-    OSF("f512x8-w16-d3", 512, 8, 3 << OSV_DELAY_SHIFT, 2, 16), // 17: direct scatter, tile parked in LDS
-    OSF("f512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8),
-    OSF("f512x8-w16-stats", 512, 8, OSV_STATS, 2, 16),      // 19
-    OSF("g512x8-w12-d3", 512, 8, OSV_WINDOW | (3 << OSV_DELAY_SHIFT), 2, 12), // f with the windowed scan
-    OSF("g512x8-w12-d3-stats", 512, 8, OSV_WINDOW | OSV_STATS | (3 << OSV_DELAY_SHIFT), 2, 12),
 };
 constexpr int kNumOsVariants = (int) (sizeof(kOsVariants) / sizeof(kOsVariants[0]));
 constexpr int kDefaultOsVariant = 0;

@@ -48,15 +48,7 @@ constexpr int OSV_NT_LOAD = 2;    // non-temporal record loads
 constexpr int OSV_NT_STORE = 4;   // non-temporal partition stores
 constexpr int OSV_NO_PREFETCH = 8; // load a tile only once it is this workgroup's turn
 constexpr int OSV_EARLY_AGG = 32;  // the last worker wave to finish hashing publishes the tile's counts
-constexpr int OSV_LATE_TICKET = 64; // draw the next tile after barrier A instead of before it
-constexpr int OSV_WIDE_FIRST = 128; // every poll of the chained scan uses the full window
-constexpr int OSV_DELAY_SHIFT = 8;  // bits 8-9: pause before the chained scan's first poll (0 none, 1-3 longer)
-constexpr int OSV_SPEC8 = 1024;      // experiment: 8-byte keys, 8 destinations, no dest_out, as constants
-constexpr int OSV_KLEN8 = 2048;      // experiment: 8-byte keys as a constant
-constexpr int OSV_NB3 = 4096;        // experiment: 8 destinations as a constant
 constexpr int OSV_NODEST = 8192;     // experiment: no dest_out
-constexpr int OSV_WINDOW = 16384;     // windowed chained scan (16-bit counts + candidate bases)
-constexpr int OS_LOOK0 = 8;
 constexpr int OSV_STATS = 16;      // diagnostic: count polls / depth / cycles of the chained scan
 
 struct OsParams {

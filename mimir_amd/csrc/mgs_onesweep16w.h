@@ -1,7 +1,7 @@
-// k_onesweep16q: the split-loop LDS-image one-sweep kernel (see
-// mgs_onesweep16p.h) with a windowed chained scan.
+// k_onesweep16q: the LDS-image one-sweep kernel with a dedicated scan wave
+// and a windowed chained scan.
 //
-// The chained scan of the other kernels walks back from tile i-1 until it
+// The plain chained scan (k_onesweep16) walks back from tile i-1 until it
 // meets a tile that has published its inclusive prefix; one poll covers 128
 // predecessors.  When tiles are handed out faster than (window / poll round
 // trip) the nearest inclusive prefix lies outside the window, the walk needs a
@@ -26,9 +26,40 @@
 #ifndef MGS_ONESWEEP16W_H
 #define MGS_ONESWEEP16W_H
 
-#include "mgs_onesweep16s.h"
+#include "mgs_onesweep16.h"
 
 namespace mgs {
+
+struct OsWalkStats { // per scan wave, flushed to Ctrl::stats once at the end of the kernel
+    unsigned long long tiles = 0, polls = 0, idle = 0, depth = 0, cycles = 0;
+    unsigned long long max_depth = 0, max_cycles = 0, max_polls = 0;
+    // windowed scan only: first polls that did not finish, by cause
+    unsigned long long fail_near = 0, fail_far = 0, fail_base = 0;
+    bool windowed = false;
+    __device__ void flush(Ctrl *ctrl) const
+    {
+        if (windowed) {
+            atomicAdd(&ctrl->head.stats[0], tiles);
+            atomicAdd(&ctrl->head.stats[1], polls);
+            atomicAdd(&ctrl->head.stats[2], idle);
+            atomicAdd(&ctrl->head.stats[3], depth);
+            atomicAdd(&ctrl->head.stats[4], cycles);
+            atomicAdd(&ctrl->head.stats[5], fail_near);
+            atomicAdd(&ctrl->head.stats[6], fail_far);
+            atomicAdd(&ctrl->head.stats[7], fail_base);
+            return;
+        }
+        atomicAdd(&ctrl->head.stats[0], tiles);
+        atomicAdd(&ctrl->head.stats[1], polls);
+        atomicAdd(&ctrl->head.stats[2], idle);
+        atomicAdd(&ctrl->head.stats[3], depth);
+        atomicAdd(&ctrl->head.stats[4], cycles);
+        atomicMax(&ctrl->head.stats[5], max_depth);
+        atomicMax(&ctrl->head.stats[6], max_cycles);
+        atomicMax(&ctrl->head.stats[7], max_polls);
+    }
+};
+
 
 constexpr unsigned long long OS_AGG16_ONES = 0x0001000100010001ull;
 constexpr unsigned long long OS_AGG16_EVEN = 0x0000ffff0000ffffull;
@@ -88,10 +119,6 @@ __device__ __forceinline__ unsigned long long os_window_walk(const OsParams &p, 
         return (x & 0xffffull) && (x & 0xffff0000ull) && (x & 0xffff00000000ull)
                && (x & 0xffff000000000000ull);
     };
-    constexpr int DELAY = (VAR >> OSV_DELAY_SHIFT) & 3;
-    if (DELAY == 1) __builtin_amdgcn_s_sleep(16);
-    if (DELAY == 2) __builtin_amdgcn_s_sleep(32);
-    if (DELAY == 3) __builtin_amdgcn_s_sleep(64);
     while (!done) {
         unsigned long long v[LOOK];
         // the far part of the window and the candidate bases first ...
