@@ -109,6 +109,25 @@ def word_records_from(vocab, ranks):
     return blob, offs, (KEY_CSTR, 0, VAL_FIXED, 8)
 
 
+def word_text(n, n_unique=1000, alpha=0.5, len_mean=5, len_sd=0.0, per_line=11, seed=44):
+    """The text wordcount reads (generator/gen_words-like): the words of
+    word_records(...) with a space after each, every `per_line`-th followed by
+    a newline instead.  Returns (text uint8, number of distinct words used)."""
+    rng = np.random.default_rng(seed)
+    vocab = unique_words(n_unique, len_mean, len_sd, seed)
+    ranks = zipf_ranks(n, n_unique, alpha, rng)
+    blob, offs, _ = word_records_from(vocab, ranks)
+    ends = offs[1:].astype(np.int64)
+    keep = np.ones(len(blob), dtype=bool)
+    for k in range(1, 9):  # drop the 8 value bytes, the key's NUL becomes the separator
+        keep[ends - k] = False
+    text = blob.copy()
+    nul = ends - 9
+    text[nul] = ord(" ")
+    text[nul[per_line - 1::per_line]] = ord("\n")
+    return text[keep], int(len(np.unique(ranks)))
+
+
 def join_records(n, n_unique=1000, alpha=0.5, len_mean=5, len_sd=0.0,
                  val_len=4, tag=0xAA, seed=45):
     """join map output <char*,SingleVal>: word, NUL, {int32 tag; 4 pad bytes

@@ -18,27 +18,10 @@ from mimir_amd import capi, datagen  # noqa: E402
 from mimir_amd.packer import DevicePacker, tokenize_text  # noqa: E402
 
 
-def corpus(n, seed=44):
-    """The words of datagen.word_records as a text: a space after each, every
-    eleventh followed by a newline instead."""
-    blob, offs, _ = datagen.word_records(n, 1_000_000, 1.0, 6, 1.0, seed=seed)
-    offs = offs.astype(np.int64)
-    # drop the 8 value bytes of every record, turn the key's NUL into the separator
-    keep = np.ones(len(blob), dtype=bool)
-    ends = offs[1:]
-    for k in range(1, 9):
-        keep[ends - k] = False
-    text = blob.copy()
-    nul = ends - 9
-    text[nul] = ord(" ")
-    text[nul[10::11]] = ord("\n")
-    return text[keep]
-
-
 def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 60_000_000
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    text = corpus(n)
+    text, _ = datagen.word_text(n, 1_000_000, 1.0, 6, 1.0, seed=44)
     pk = DevicePacker(capi.Layout.make(capi.KEY_CSTR, 0, capi.VAL_FIXED, 8), 2, -1, 4096, 1)
     d = torch.from_numpy(text).cuda()
     records = torch.empty(len(text) + 9 * n + 64, dtype=torch.uint8, device="cuda")
