@@ -117,7 +117,9 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    """The in-tree build, or another build of the same ABI named by MGS_LIBRARY
+    (for A/B timing of two builds on one box)."""
+    return os.environ.get("MGS_LIBRARY") or _build.LIB
 
 
 def load():
