@@ -286,6 +286,33 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
                      uint64_t *n_groups, uint64_t *cuts, int max_cuts, int *n_cuts,
                      void *stream);
 
+/* ---- send side with a combiner ----------------------------------------------
+ * One round of CombineCollectiveShuffler::write
+ * (src/combinecollectiveshuffler.h:63-180) for an 8-byte value and a combiner
+ * that is one of the operations below (the reference calls a user callback,
+ * :139; wordcount's, examples/wordcount.cpp:96-100, is MGS_COMBINE_SUM_U64;
+ * a job declares the operation instead of passing a callback).  Records
+ * [start, n_end): a record whose destination is this rank goes to d_local_out
+ * unchanged (:67-83); of the others only the first with each key is written
+ * to its partition, in emit order (:94-135), every later one is combined into
+ * it (:137-151); the round ends before the first NEW key that does not fit its
+ * partition (:122-127) -- out->next -- and the next call starts with no key
+ * known, as after garbage_collection() (:237).  Partitions are written from
+ * their beginning (one round per call); out->packed_records counts the new
+ * keys (kvcount, :134).  Arguments as mgs_pack_device.  At most 64 ranks; the
+ * records of one call must be under 4 GiB.  Blocking.  Feed about a round's
+ * worth of records per call: keys that first occur after the round's end cost
+ * table work for nothing. */
+typedef enum mgs_combine_op {
+    MGS_COMBINE_SUM_U64 = 0,
+    MGS_COMBINE_MIN_U64 = 1,
+    MGS_COMBINE_MAX_U64 = 2
+} mgs_combine_op;
+
+int mgs_combine_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
+                       uint64_t n_end, uint64_t start, int op, void *d_send_image,
+                       void *d_local_out, int64_t local_cap, void *stream, mgs_round *out);
+
 /* ---- host-staged front end: what a Writable::write() shim calls -----------
  * The reference serialises every pair into the send buffer inside write()
  * (src/collectiveshuffler.h:143-146) because the caller's pointers die when

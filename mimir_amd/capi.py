@@ -14,6 +14,7 @@ MGS_MAX_RANKS = 256
 KEY_FIXED, KEY_CSTR = 0, 1
 VAL_VOID, VAL_FIXED, VAL_CSTR = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_ONESWEEP16, ALGO_ONESWEEPV = 0, 1, 2, 3
+COMBINE_SUM_U64, COMBINE_MIN_U64, COMBINE_MAX_U64 = 0, 1, 2
 
 OK = 0
 ERR_ARG, ERR_HIP, ERR_RECORD_SIZE, ERR_LOCAL_OVERFLOW = -1, -2, -3, -4
@@ -105,6 +106,8 @@ SYMBOLS = {
                                     C.c_int64, C.c_int64, C.POINTER(C.c_uint64),
                                     C.POINTER(PageCut), C.c_int,
                                     C.POINTER(C.c_int), _VP]),
+    "mgs_combine_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, C.c_int, _VP, _VP,
+                                     C.c_int64, _VP, C.POINTER(Round)]),
     "mgs_group_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, _VP, C.c_uint64, _VP,
                                    C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.c_int, C.POINTER(C.c_int), _VP]),

@@ -17,6 +17,7 @@
 #include "mgs_unpack.h"
 #include "mgs_tokenize.h"
 #include "mgs_group.h"
+#include "mgs_combine.h"
 
 using namespace mgs;
 
@@ -1030,6 +1031,130 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
     }
     for (uint64_t k = 0; k < nc; k++) cuts[k] = h->h_unp[2 + k];
     *n_cuts = (int) nc;
+    return MGS_OK;
+}
+
+// ---- send side with a combiner ----------------------------------------------------
+int mgs_combine_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
+                       uint64_t start, int op, void *d_send_image, void *d_local_out, int64_t local_cap,
+                       void *stream_v, mgs_round *out)
+{
+    if (!h || !out || !d_send_image || (n_end > start && !d_records)) {
+        if (h) h->err = "mgs_combine_device: NULL argument";
+        return MGS_ERR_ARG;
+    }
+    const mgs_layout &L = h->desc.layout;
+    const int P = h->desc.nranks, self = h->desc.rank;
+    if (L.val_kind != MGS_VAL_FIXED || L.val_bytes != 8 || P > OS_MAXP || op < MGS_COMBINE_SUM_U64
+        || op > MGS_COMBINE_MAX_U64) {
+        h->err = "mgs_combine_device: needs an 8-byte value, at most 64 ranks and a declared operation";
+        return MGS_ERR_ARG;
+    }
+    if (start > n_end || (!h->fixed_len && n_end > start && !d_rec_off) || (self >= 0 && n_end > start && !d_local_out)
+        || local_cap < 0) {
+        h->err = "mgs_combine_device: start > n_end, or d_rec_off / d_local_out missing";
+        return MGS_ERR_ARG;
+    }
+    const uint64_t n = n_end - start;
+    if (n > (1ull << 30) || (h->fixed_len && n * h->fixed_len >= (1ull << 32))) {
+        h->err = "mgs_combine_device: at most 2^30 records and 4 GiB per call";
+        return MGS_ERR_ARG;
+    }
+    DeviceGuard g(h->desc.device);
+    if (!g.ok) {
+        h->err = "mgs_combine_device: hipSetDevice failed";
+        return MGS_ERR_HIP;
+    }
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
+    memset(out, 0, sizeof(*out));
+    out->next = start;
+    if (n == 0) return MGS_OK;
+
+    CmbParams p;
+    memset(&p, 0, sizeof(p));
+    GrpParams &q = p.g;
+    // records [start, n_end) as records 0 .. n-1: offsets stay absolute into the blob
+    q.blob = static_cast<const uint8_t *>(d_records) + (h->fixed_len ? start * h->fixed_len : 0);
+    q.rec_off = h->fixed_len ? nullptr : d_rec_off + start;
+    q.fixed_len = h->fixed_len;
+    q.n = (uint32_t) n;
+    q.lay = L;
+    q.vbytes = 8;
+    uint32_t log_slots = 10;
+    while ((1ull << log_slots) < 2 * n) log_slots++;
+    const size_t slots = (size_t) 1 << log_slots;
+    q.slot_mask = (uint32_t) (slots - 1);
+    q.slot_shift = 32 - log_slots;
+    q.ntiles = (uint32_t) ((n + GRP_TILE - 1) / GRP_TILE);
+    q.ctrl = h->d_ctrl;
+    q.fm = h->fm;
+    p.start = start;
+    p.P = (uint32_t) P;
+    p.self = self;
+    p.buf_size = h->desc.buf_size;
+    p.local_cap = local_cap;
+    p.op = op;
+    p.ncol = (uint32_t) P + 2;
+    p.image = static_cast<uint8_t *>(d_send_image);
+    p.local_out = static_cast<uint8_t *>(d_local_out);
+    p.round = &h->d_ctrl->result;
+
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t cols = ((size_t) q.ntiles + 1) * p.ncol;
+    const size_t need = up(sizeof(unsigned long long)) + up(slots * sizeof(uint32_t)) + 2 * up(n * sizeof(uint32_t))
+                        + up(n) + up((size_t) q.ntiles * (GRP_TILE / 64) * sizeof(uint64_t)) + up(cols * sizeof(uint32_t))
+                        + up(cols * sizeof(unsigned long long)) + up(n * sizeof(unsigned long long));
+    if (h->pending) { // one call in flight per handle: the control block is shared
+        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    }
+    if (need > h->grp_bytes) {
+        if (h->d_grp) {
+            MGS_HIP(h, hipDeviceSynchronize());
+            MGS_HIP(h, hipFree(h->d_grp));
+            h->d_grp = nullptr;
+            h->grp_bytes = 0;
+        }
+        MGS_HIP(h, hipMalloc(&h->d_grp, need));
+        h->grp_bytes = need;
+    }
+    uint8_t *w = h->d_grp;
+    p.end = reinterpret_cast<unsigned long long *>(w);         w += up(sizeof(unsigned long long));
+    q.table = reinterpret_cast<uint32_t *>(w);                 w += up(slots * sizeof(uint32_t));
+    q.slot_or_rank = reinterpret_cast<uint32_t *>(w);          w += up(n * sizeof(uint32_t));
+    p.pos = reinterpret_cast<uint32_t *>(w);                   w += up(n * sizeof(uint32_t));
+    q.dest_out = w;                                            w += up(n);
+    q.first_bits = reinterpret_cast<uint64_t *>(w);            w += up((size_t) q.ntiles * (GRP_TILE / 64) * sizeof(uint64_t));
+    p.col = reinterpret_cast<uint32_t *>(w);                   w += up(cols * sizeof(uint32_t));
+    p.col_x = reinterpret_cast<unsigned long long *>(w);       w += up(cols * sizeof(unsigned long long));
+    p.acc = reinterpret_cast<unsigned long long *>(w);         w += up(n * sizeof(unsigned long long));
+
+    const unsigned wide = (unsigned) std::min<uint64_t>((n + GRP_THREADS - 1) / GRP_THREADS,
+                                                        (uint64_t) std::max(h->num_cus, 1) * 32);
+    MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
+    MGS_HIP(h, hipMemsetAsync(q.table, 0xFF, slots * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_grp_insert, dim3(wide), dim3(GRP_THREADS), 0, stream, q);
+    hipLaunchKernelGGL(k_cmb_cols, dim3(q.ntiles), dim3(GRP_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(k_cmb_colscan, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(k_cmb_place, dim3(q.ntiles), dim3(GRP_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(k_cmb_reduce, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(k_cmb_emit, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(k_cmb_final, dim3(1), dim3(GRP_THREADS), 0, stream, p);
+    MGS_HIP(h, hipGetLastError());
+    MGS_HIP(h, hipMemcpyAsync(&h->h_ctrl->result, &h->d_ctrl->result, sizeof(mgs_round), hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipMemcpyAsync(&h->h_ctrl->head.error, &h->d_ctrl->head.error, sizeof(int32_t),
+                              hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipStreamSynchronize(stream));
+    const int derr = h->h_ctrl->head.error;
+    if (derr != 0) {
+        switch (derr) {
+        case MGS_ERR_MALFORMED: h->err = "a record does not match the layout"; break;
+        case MGS_ERR_RECORD_SIZE: h->err = fmt("KV size is larger than buf_size (%lld)", (long long) p.buf_size); break;
+        case MGS_ERR_LOCAL_OVERFLOW: h->err = "d_local_out is too small for the records that stay on this rank"; break;
+        default: h->err = fmt("device error %d", derr);
+        }
+        return derr;
+    }
+    *out = h->h_ctrl->result;
     return MGS_OK;
 }
 

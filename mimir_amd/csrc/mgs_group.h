@@ -68,6 +68,8 @@ struct GrpParams {
     uint32_t max_cuts;
     uint64_t *result;        // [0] groups, [1] cuts
     Ctrl *ctrl;
+    uint8_t *dest_out;       // optional [n]: hashlittle(key) % fm.d of every record (the combiner needs it)
+    FastMod fm;
 };
 
 struct __attribute__((packed)) GrpU64 { unsigned long long v; };
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_insert(GrpParams p)
             continue;
         }
         const uint32_t h = hashlittle_bytes(key, klen);
+        if (p.dest_out) p.dest_out[i] = (uint8_t) fastmod(h, p.fm);
         uint32_t s = (h * 0x9E3779B1u) >> p.slot_shift;
         for (uint32_t probes = 0; probes <= p.slot_mask; probes++) { // the table is at most half full
             uint32_t cur = __hip_atomic_load(p.table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

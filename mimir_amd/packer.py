@@ -130,6 +130,20 @@ class DevicePacker:
         self._check(self.lib.mgs_pack_device(*args, C.byref(r)))
         return RoundResult(r, self.nranks)
 
+    def combine(self, records, n_end, send_image, start=0, rec_off=None, local_out=None,
+                op=capi.COMBINE_SUM_U64):
+        """Blocking CombineCollectiveShuffler::write over records [start, n_end): one
+        round, partitions written from their beginning."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if not s:  # see _args
+            torch.cuda.current_stream(self.device).synchronize()
+        r = capi.Round()
+        self._check(self.lib.mgs_combine_device(
+            self.h, _ptr(records), _ptr(rec_off), n_end, start, op, _ptr(send_image),
+            _ptr(local_out), local_out.numel() if local_out is not None else 0,
+            C.c_void_p(s), C.byref(r)))
+        return RoundResult(r, self.nranks)
+
     def pack_async(self, records, n_end, send_image, start=0, rec_off=None,
                    init_offset=None, local_out=None, dest_out=None,
                    algo=capi.ALGO_AUTO, stream=None):

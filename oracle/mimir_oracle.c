@@ -417,3 +417,72 @@ done:
     free(group_of);
     return rc;
 }
+
+uint64_t mo_combine_round(const mo_layout *lay, const uint8_t *blob,
+                          const uint64_t *rec_off, int64_t fixed_len, uint64_t n,
+                          uint64_t start, uint32_t nranks, int32_t self,
+                          int64_t buf_size, int op, uint8_t *send_image,
+                          int64_t *send_offset, uint8_t *local_out,
+                          int64_t local_cap, int64_t *local_bytes,
+                          uint64_t *local_records, uint64_t *packed_records)
+{
+    if (lay->val_kind != MO_VAL_FIXED || lay->val_bytes != 8 || !send_image) return UINT64_MAX;
+    const uint32_t nbucket = 1024 * 1024; /* BUCKET_COUNT; HashBucket<CombinerVal>() has scale 1 (:47) */
+    typedef struct { uint8_t *kv; int64_t klen; int64_t next; } entry;
+    int64_t *bucket = (int64_t *) malloc(sizeof(int64_t) * nbucket);
+    entry *ent = (entry *) malloc(sizeof(entry) * (n - start ? n - start : 1));
+    int64_t nent = 0;
+    uint64_t i = start, rc = UINT64_MAX;
+    if (!bucket || !ent) goto done;
+    for (uint32_t b = 0; b < nbucket; b++) bucket[b] = -1;
+    for (uint32_t d = 0; d < nranks; d++) send_offset[d] = 0;
+    *local_bytes = 0;
+    *local_records = 0;
+    *packed_records = 0;
+    for (; i < n; i++) {
+        uint64_t off;
+        int64_t len;
+        rec_span(rec_off, fixed_len, i, &off, &len);
+        const uint8_t *rec = blob + off;
+        const int64_t klen = mo_key_len(lay, rec, len);
+        if (klen < 0 || klen + 8 != len) goto done;
+        const uint32_t h = mo_hashlittle(rec, (size_t) klen, 0);
+        const int32_t target = (int32_t) (h % nranks);
+        if (target == self) { /* :67-83 */
+            if (local_out) {
+                if (*local_bytes + len > local_cap) goto done;
+                memcpy(local_out + *local_bytes, rec, (size_t) len);
+            }
+            *local_bytes += len;
+            *local_records += 1;
+            continue;
+        }
+        if (len > buf_size) goto done; /* :86-88 */
+        const uint32_t ib = h % nbucket;
+        int64_t e = bucket[ib];
+        while (e >= 0 && !(ent[e].klen == klen && memcmp(ent[e].kv, rec, (size_t) klen) == 0)) e = ent[e].next;
+        if (e < 0) { /* a new key, :94-135 */
+            if (send_offset[target] + len > buf_size) break; /* the round ends here, :122-127 */
+            uint8_t *kv = send_image + (int64_t) target * buf_size + send_offset[target];
+            memcpy(kv, rec, (size_t) len);
+            send_offset[target] += len;
+            ent[nent].kv = kv;
+            ent[nent].klen = klen;
+            ent[nent].next = bucket[ib];
+            bucket[ib] = nent++;
+            *packed_records += 1;
+        }
+        else { /* combine in place, :137-151 */
+            uint64_t a, b, r;
+            memcpy(&a, ent[e].kv + klen, 8);
+            memcpy(&b, rec + klen, 8);
+            r = op == MO_COMBINE_SUM_U64 ? a + b : op == MO_COMBINE_MIN_U64 ? (a < b ? a : b) : (a > b ? a : b);
+            memcpy(ent[e].kv + klen, &r, 8);
+        }
+    }
+    rc = i;
+done:
+    free(bucket);
+    free(ent);
+    return rc;
+}

@@ -163,6 +163,28 @@ int64_t mo_kmv_convert(const mo_layout *lay, const uint8_t *blob,
                        uint8_t *values_out, uint64_t *cut_group_out,
                        int64_t max_cuts, int64_t *n_cuts);
 
+/* One round of CombineCollectiveShuffler::write
+ * (src/combinecollectiveshuffler.h:63-180) over records [start, n), for an
+ * 8-byte value and a combiner that is one of the declared operations below
+ * (the reference calls a user callback, :139; wordcount's is a sum,
+ * examples/wordcount.cpp:96-100).  A record whose destination is `self` goes
+ * to local_out as it is (:67-83).  Any other record is looked up in the
+ * round's hash bucket (:91-92): a new key is appended to its partition and
+ * remembered (:94-135), a known key has its value combined in place (:137-151;
+ * a fixed-width value never changes size, so no slices arise).  The round
+ * ends before the first NEW key that does not fit its partition (:122-127);
+ * garbage_collection() then clears the bucket (:237), so the next round
+ * starts with no keys known.  Arguments and return as mo_pack_round;
+ * packed_records counts the new keys (kvcount, :134). */
+enum { MO_COMBINE_SUM_U64 = 0, MO_COMBINE_MIN_U64 = 1, MO_COMBINE_MAX_U64 = 2 };
+uint64_t mo_combine_round(const mo_layout *lay, const uint8_t *blob,
+                          const uint64_t *rec_off, int64_t fixed_len, uint64_t n,
+                          uint64_t start, uint32_t nranks, int32_t self,
+                          int64_t buf_size, int op, uint8_t *send_image,
+                          int64_t *send_offset, uint8_t *local_out,
+                          int64_t local_cap, int64_t *local_bytes,
+                          uint64_t *local_records, uint64_t *packed_records);
+
 #ifdef __cplusplus
 }
 #endif

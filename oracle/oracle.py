@@ -86,6 +86,12 @@ class Oracle:
         L.mo_page_cuts.restype = C.c_int64
         L.mo_page_cuts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_int64]
+        L.mo_combine_round.restype = C.c_uint64
+        L.mo_combine_round.argtypes = [
+            C.POINTER(Layout), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64,
+            C.c_uint64, C.c_uint32, C.c_int32, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
+            C.POINTER(C.c_uint64)]
         L.mo_kmv_convert.restype = C.c_int64
         L.mo_kmv_convert.argtypes = [C.POINTER(Layout), C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p,
@@ -94,6 +100,26 @@ class Oracle:
         L.mo_tokenize.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_int64]
         self.L = L
+
+    def combine_round(self, lay, blob, rec_off, n, start, nranks, self_rank, buf_size, op=0):
+        """One round of CombineCollectiveShuffler::write; same result dict as pack_round."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = self._offs(rec_off)
+        img = np.zeros(nranks * buf_size, dtype=np.uint8)
+        so = np.zeros(nranks, dtype=np.int64)
+        loc = np.zeros(max(len(blob), 1), dtype=np.uint8)
+        lb, lr, pr = C.c_int64(), C.c_uint64(), C.c_uint64()
+        nxt = self.L.mo_combine_round(
+            C.byref(lay), blob.ctypes.data, offs.ctypes.data if offs is not None else None,
+            lay.fixed_len() if offs is None else 0, n, start, nranks, self_rank, buf_size, op,
+            img.ctypes.data, so.ctypes.data, loc.ctypes.data, len(loc),
+            C.byref(lb), C.byref(lr), C.byref(pr))
+        if nxt == 2**64 - 1:
+            raise ValueError("oracle: combine_round failed")
+        return {"next": int(nxt), "send_offset": so, "local_bytes": lb.value,
+                "local_records": lr.value, "packed_records": pr.value,
+                "partitions": [img[d * buf_size:d * buf_size + so[d]] for d in range(nranks)],
+                "local": loc[:lb.value]}
 
     def kmv_convert(self, lay, blob, rec_off, n, hashscale=1, page_bytes=64 << 20):
         """KMVContainer::convert: (group_first u32[G], group_start u64[G+1],
