@@ -169,19 +169,93 @@ __global__ __launch_bounds__(GRP_THREADS) void k_cmb_place(CmbParams p)
     }
 }
 
+__device__ __forceinline__ unsigned long long cmb_apply(int op, unsigned long long a, unsigned long long b)
+{
+    return op == MGS_COMBINE_SUM_U64 ? a + b : op == MGS_COMBINE_MIN_U64 ? (a < b ? a : b) : (a > b ? a : b);
+}
+
+__device__ __forceinline__ void cmb_atomic(int op, unsigned long long *at, unsigned long long v)
+{
+    if (op == MGS_COMBINE_SUM_U64) atomicAdd(at, v);
+    else if (op == MGS_COMBINE_MIN_U64) atomicMin(at, v);
+    else atomicMax(at, v);
+}
+
+// Skewed keys would send millions of atomics to one address, and atomics on one
+// address are served one after the other.  So a workgroup takes a contiguous
+// stretch of the records and combines in LDS first: a small table keyed by the
+// accumulator's index (a few probes; what finds no place goes to memory
+// directly), flushed with one atomic per entry.  In front of that a wave
+// combines the lanes that hit the same accumulator (up to CMB_PEEL distinct ones
+// per step; the frequent ones are met early because they hold many lanes).
+constexpr int CMB_PEEL = 4;
+constexpr int CMB_LDS_LOG = 11, CMB_LDS_SLOTS = 1 << CMB_LDS_LOG, CMB_LDS_PROBES = 4;
+
+__device__ __forceinline__ void cmb_lds_atomic(int op, unsigned long long *at, unsigned long long v)
+{
+    if (op == MGS_COMBINE_SUM_U64) atomicAdd(at, v);
+    else if (op == MGS_COMBINE_MIN_U64) atomicMin(at, v);
+    else atomicMax(at, v);
+}
+
 __global__ __launch_bounds__(GRP_THREADS) void k_cmb_reduce(CmbParams p)
 {
+    __shared__ uint32_t skey[CMB_LDS_SLOTS];
+    __shared__ unsigned long long sval[CMB_LDS_SLOTS];
     const GrpParams &g = p.g;
     const uint64_t end = *p.end;
-    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < end; i += stride) {
-        if ((g.first_bits[i / 64] >> (i & 63)) & 1ull) continue; // kept records are written, not combined
-        const uint32_t first = g.table[g.slot_or_rank[i]];
-        const unsigned long long v = reinterpret_cast<const GrpU64 *>(g.blob + grp_offset(g, i + 1) - 8)->v;
-        if (p.op == MGS_COMBINE_SUM_U64) atomicAdd(p.acc + first, v);
-        else if (p.op == MGS_COMBINE_MIN_U64) atomicMin(p.acc + first, v);
-        else atomicMax(p.acc + first, v);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long neutral = p.op == MGS_COMBINE_MIN_U64 ? ~0ull : 0ull;
+    for (int e = threadIdx.x; e < CMB_LDS_SLOTS; e += GRP_THREADS) {
+        skey[e] = GRP_EMPTY;
+        sval[e] = neutral;
     }
+    __syncthreads();
+    // this workgroup's stretch, a multiple of the workgroup size
+    const uint64_t per = ((end + gridDim.x - 1) / gridDim.x + GRP_THREADS - 1) / GRP_THREADS * GRP_THREADS;
+    const uint64_t s0 = (uint64_t) blockIdx.x * per, s1 = min(end, s0 + per);
+    for (uint64_t i0 = s0; i0 < s1; i0 += GRP_THREADS) { // whole waves stay together
+        const uint64_t i = i0 + threadIdx.x;
+        // kept records are written, not combined
+        bool todo = i < s1 && !((g.first_bits[i / 64] >> (i & 63)) & 1ull);
+        uint32_t first = 0;
+        unsigned long long v = neutral;
+        if (todo) {
+            first = g.table[g.slot_or_rank[i]];
+            v = reinterpret_cast<const GrpU64 *>(g.blob + grp_offset(g, i + 1) - 8)->v;
+        }
+        bool speaker = false; // this lane carries a combined value to the table
+        for (int it = 0; it < CMB_PEEL; it++) {
+            const uint64_t rest = __ballot(todo);
+            if (rest == 0) break;
+            const int leader = __ffsll((unsigned long long) rest) - 1;
+            const uint32_t f = (uint32_t) __shfl((int) first, leader);
+            const bool in = todo && first == f;
+            unsigned long long r = in ? v : neutral;
+            for (int o = 1; o < 64; o <<= 1) r = cmb_apply(p.op, r, __shfl_xor(r, o));
+            if (lane == leader) {
+                v = r;
+                speaker = true;
+            }
+            todo = todo && !in;
+        }
+        if (todo || speaker) {
+            uint32_t s = (first * 0x9E3779B1u) >> (32 - CMB_LDS_LOG);
+            bool placed = false;
+            for (int pr = 0; pr < CMB_LDS_PROBES && !placed; pr++) {
+                const uint32_t cur = atomicCAS(&skey[s], GRP_EMPTY, first);
+                if (cur == GRP_EMPTY || cur == first) {
+                    cmb_lds_atomic(p.op, &sval[s], v);
+                    placed = true;
+                }
+                s = (s + 1) & (CMB_LDS_SLOTS - 1);
+            }
+            if (!placed) cmb_atomic(p.op, p.acc + first, v);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CMB_LDS_SLOTS; e += GRP_THREADS)
+        if (skey[e] != GRP_EMPTY) cmb_atomic(p.op, p.acc + skey[e], sval[e]);
 }
 
 __global__ __launch_bounds__(GRP_THREADS) void k_cmb_emit(CmbParams p)
