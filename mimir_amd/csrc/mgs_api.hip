@@ -948,7 +948,7 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
         }
     }
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t need = up((2 + kUnpMaxCuts) * sizeof(uint64_t)) + 2 * up(slots * sizeof(uint32_t))
+    const size_t need = up((2 + kUnpMaxCuts) * sizeof(uint64_t)) + 3 * up(slots * sizeof(uint32_t))
                         + 3 * up((size_t) n_records * sizeof(uint32_t)) + up(((size_t) p.ntiles + 1) * sizeof(uint32_t))
                         + up((size_t) p.ntiles * (GRP_TILE / 64) * sizeof(uint64_t))
                         + up(sort_bytes);
@@ -968,7 +968,7 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
     uint8_t *q = h->d_grp;
     p.result = reinterpret_cast<uint64_t *>(q);
     p.cuts = p.result + 2;                               q += up((2 + kUnpMaxCuts) * sizeof(uint64_t));
-    p.table = reinterpret_cast<uint32_t *>(q);           q += up(slots * sizeof(uint32_t));
+    p.table = reinterpret_cast<unsigned long long *>(q); q += up(slots * sizeof(unsigned long long));
     p.rank_table = reinterpret_cast<uint32_t *>(q);      q += up(slots * sizeof(uint32_t));
     p.slot_or_rank = reinterpret_cast<uint32_t *>(q);    q += up((size_t) n_records * sizeof(uint32_t));
     p.sorted_rank = reinterpret_cast<uint32_t *>(q);     q += up((size_t) n_records * sizeof(uint32_t));
@@ -981,7 +981,7 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
                                                         (uint64_t) std::max(h->num_cus, 1) * 32);
     MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
     MGS_HIP(h, hipMemsetAsync(p.result, 0, 2 * sizeof(uint64_t), stream));
-    MGS_HIP(h, hipMemsetAsync(p.table, 0xFF, slots * sizeof(uint32_t), stream));
+    MGS_HIP(h, hipMemsetAsync(p.table, 0xFF, slots * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(k_grp_insert, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
     hipLaunchKernelGGL(k_grp_count, dim3(p.ntiles), dim3(GRP_THREADS), 0, stream, p);
     hipLaunchKernelGGL(k_grp_scan, dim3(1), dim3(1024), 0, stream, p);
@@ -1101,7 +1101,7 @@ int mgs_combine_device(mgs_handle *h, const void *d_records, const uint32_t *d_r
 
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t cols = ((size_t) q.ntiles + 1) * p.ncol;
-    const size_t need = up(sizeof(unsigned long long)) + up(slots * sizeof(uint32_t)) + 2 * up(n * sizeof(uint32_t))
+    const size_t need = up(sizeof(unsigned long long)) + 3 * up(slots * sizeof(uint32_t)) + 2 * up(n * sizeof(uint32_t))
                         + up(n) + up((size_t) q.ntiles * (GRP_TILE / 64) * sizeof(uint64_t)) + up(cols * sizeof(uint32_t))
                         + up(cols * sizeof(unsigned long long)) + up(n * sizeof(unsigned long long));
     if (h->pending) { // one call in flight per handle: the control block is shared
@@ -1119,7 +1119,8 @@ int mgs_combine_device(mgs_handle *h, const void *d_records, const uint32_t *d_r
     }
     uint8_t *w = h->d_grp;
     p.end = reinterpret_cast<unsigned long long *>(w);         w += up(sizeof(unsigned long long));
-    q.table = reinterpret_cast<uint32_t *>(w);                 w += up(slots * sizeof(uint32_t));
+    q.table = reinterpret_cast<unsigned long long *>(w);       w += up(slots * sizeof(unsigned long long));
+    q.rank_table = reinterpret_cast<uint32_t *>(w);            w += up(slots * sizeof(uint32_t));
     q.slot_or_rank = reinterpret_cast<uint32_t *>(w);          w += up(n * sizeof(uint32_t));
     p.pos = reinterpret_cast<uint32_t *>(w);                   w += up(n * sizeof(uint32_t));
     q.dest_out = w;                                            w += up(n);
@@ -1131,7 +1132,7 @@ int mgs_combine_device(mgs_handle *h, const void *d_records, const uint32_t *d_r
     const unsigned wide = (unsigned) std::min<uint64_t>((n + GRP_THREADS - 1) / GRP_THREADS,
                                                         (uint64_t) std::max(h->num_cus, 1) * 32);
     MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
-    MGS_HIP(h, hipMemsetAsync(q.table, 0xFF, slots * sizeof(uint32_t), stream));
+    MGS_HIP(h, hipMemsetAsync(q.table, 0xFF, slots * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(k_grp_insert, dim3(wide), dim3(GRP_THREADS), 0, stream, q);
     hipLaunchKernelGGL(k_cmb_cols, dim3(q.ntiles), dim3(GRP_THREADS), 0, stream, p);
     hipLaunchKernelGGL(k_cmb_colscan, dim3(1), dim3(1024), 0, stream, p);

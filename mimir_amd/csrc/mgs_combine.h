@@ -13,8 +13,9 @@
 // On the device, over records [start, n_end):
 //   k_grp_insert   (mgs_group.h) the hash table: slot of every record, the slot
 //                  holds the first record with the key; destination per record
-//   k_cmb_cols     kept = local or first with its key; per tile of 2048 records
-//                  the kept bytes per destination (+ two count columns)
+//   k_cmb_cols     kept = local or first with its key (the first leaves its index
+//                  beside the slot); per tile of 2048 records the kept bytes per
+//                  destination (+ two count columns)
 //   k_cmb_colscan  exclusive sums of every column over the tiles
 //   k_cmb_place    byte position of every kept record in its partition / the
 //                  local stream (stable: emit order); the first remote record
@@ -75,7 +76,10 @@ __global__ __launch_bounds__(GRP_THREADS) void k_cmb_cols(CmbParams p)
         if (i < g.n) {
             const uint32_t d = g.dest_out[i];
             const bool local = (int32_t) d == p.self;
-            kept = local || g.table[g.slot_or_rank[i]] == (uint32_t) i;
+            const uint32_t slot = g.slot_or_rank[i];
+            const bool first = (uint32_t) g.table[slot] == grp_place(g, i);
+            kept = local || first;
+            if (first && !local) g.rank_table[slot] = (uint32_t) i; // where the key's accumulator is
             if (kept) {
                 atomicAdd(&sum[d], cmb_len(g, i));
                 atomicAdd(&sum[p.P + (local ? 0u : 1u)], 1u);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(GRP_THREADS) void k_cmb_reduce(CmbParams p)
         uint32_t first = 0;
         unsigned long long v = neutral;
         if (todo) {
-            first = g.table[g.slot_or_rank[i]];
+            first = g.rank_table[g.slot_or_rank[i]];
             v = reinterpret_cast<const GrpU64 *>(g.blob + grp_offset(g, i + 1) - 8)->v;
         }
         bool speaker = false; // this lane carries a combined value to the table

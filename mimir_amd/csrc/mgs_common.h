@@ -98,27 +98,6 @@ __host__ __device__ __forceinline__ uint32_t hash_rec16(uint32_t w0, uint32_t w1
     return c;
 }
 
-// The same hash with the key's byte count turned into one mask per word on the
-// host (word w keeps its first clamp(klen - 4w, 0, 4) bytes): no per-record
-// selects.  km[3] is only used for keys longer than 12 bytes.
-__host__ __device__ __forceinline__ uint32_t hash_rec16m(uint32_t w0, uint32_t w1, uint32_t w2,
-                                                         uint32_t w3, uint32_t klen,
-                                                         const uint32_t (&km)[4])
-{
-    uint32_t a, b, c;
-    a = b = c = 0xdeadbeefu + klen;
-    if (klen > 12) {
-        a += w0; b += w1; c += w2;
-        MGS_MIX(a, b, c);
-        a += w3 & km[3];
-    }
-    else {
-        a += w0 & km[0]; b += w1 & km[1]; c += w2 & km[2];
-    }
-    MGS_FINAL(a, b, c);
-    return c;
-}
-
 // ---------------------------------------------------------------------------
 // dest = hash % (uint32_t) nranks (src/baseshuffler.h:277) without a divide:
 // round-up multiply-high division (exact for every 32-bit numerator), then

@@ -19,12 +19,13 @@
 //   values          the records' values, grouped
 //   cuts            the groups at which a new value buffer begins
 //
-//   k_grp_insert  open-addressing table of record indices: a slot holds the
-//                 smallest index seen so far of the records with one key
-//                 (keys are compared in the stream itself); slot of every record
+//   k_grp_insert  open-addressing table: a slot holds the key's hash and the place
+//                 (byte offset or index) of the first record seen so far with
+//                 that key -- keys are compared in the stream itself, and only
+//                 when the hashes agree; slot of every record
 //   k_grp_count / k_grp_scan / k_grp_rank
 //                 a record is a first occurrence iff its slot holds its own
-//                 index; prefix sum over those flags = the group's rank, left in
+//                 place; prefix sum over those flags = the group's rank, left in
 //                 a second table by the first record
 //   k_grp_keys    rank of every record's group (the sort key)
 //   (library)     stable radix sort of (rank, record index) pairs on the bits
@@ -41,6 +42,7 @@
 namespace mgs {
 
 constexpr uint32_t GRP_EMPTY = 0xFFFFFFFFu;
+constexpr unsigned long long GRP_EMPTY64 = ~0ull;
 constexpr int GRP_THREADS = 256, GRP_ITEMS = 8, GRP_TILE = GRP_THREADS * GRP_ITEMS;
 
 struct GrpParams {
@@ -50,7 +52,7 @@ struct GrpParams {
     uint32_t n;              // records
     mgs_layout lay;
     uint32_t vbytes;         // value bytes per record (0 = no value)
-    uint32_t *table;         // [slots] smallest record index of a key, or GRP_EMPTY
+    unsigned long long *table; // [slots] hash << 32 | place of the first record with a key (grp_place), or GRP_EMPTY64
     uint32_t *rank_table;    // [slots] rank of the key's group
     uint32_t slot_mask, slot_shift;
     uint32_t *slot_or_rank;  // [n] slot of record i, later the rank of its group
@@ -79,6 +81,19 @@ __device__ __forceinline__ uint64_t grp_offset(const GrpParams &p, uint64_t i)
     return p.rec_off ? (uint64_t) p.rec_off[i] : i * (uint64_t) p.fixed_len;
 }
 
+// Where a record's key is, as the table keeps it: the record's byte offset
+// (variable width: the key is found without another look-up) or its index
+// (fixed width).  Ascends with the record index either way.
+__device__ __forceinline__ uint32_t grp_place(const GrpParams &p, uint64_t i)
+{
+    return p.rec_off ? p.rec_off[i] : (uint32_t) i;
+}
+
+__device__ __forceinline__ const uint8_t *grp_key_at(const GrpParams &p, uint32_t place)
+{
+    return p.blob + (p.rec_off ? (uint64_t) place : (uint64_t) place * p.fixed_len);
+}
+
 // Key of record i: first byte and length (false: the record does not match the layout).
 __device__ __forceinline__ bool grp_key(const GrpParams &p, uint32_t i, const uint8_t *&key, uint32_t &klen)
 {
@@ -88,14 +103,17 @@ __device__ __forceinline__ bool grp_key(const GrpParams &p, uint32_t i, const ui
     return gen_key_len(p.lay, key, (uint32_t) (o1 - o0), klen);
 }
 
-__device__ __forceinline__ bool grp_same_key(const uint8_t *a, uint32_t alen, const uint8_t *b, uint32_t blen)
+// Is the key at b (a record's first byte) the key a[0..alen)?  Only alen is
+// needed: keys of one layout that agree over the length of one of them, its
+// terminating NULs included, are equal; the first difference lies inside both.
+// `b_room` = bytes that may be read at b.
+__device__ __forceinline__ bool grp_same_key(const uint8_t *a, uint32_t alen, const uint8_t *b, uint64_t b_room)
 {
-    if (alen != blen) return false;
     uint32_t j = 0;
-    for (; j + 8 <= alen; j += 8)
+    for (; j + 8 <= alen && j + 8 <= b_room; j += 8)
         if (reinterpret_cast<const GrpU64 *>(a + j)->v != reinterpret_cast<const GrpU64 *>(b + j)->v) return false;
     for (; j < alen; j++)
-        if (a[j] != b[j]) return false;
+        if (j >= b_room || a[j] != b[j]) return false;
     return true;
 }
 
@@ -106,6 +124,7 @@ __device__ __forceinline__ bool grp_same_key(const uint8_t *a, uint32_t alen, co
 __global__ __launch_bounds__(GRP_THREADS) void k_grp_insert(GrpParams p)
 {
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    const uint64_t blob_bytes = grp_offset(p, p.n); // the records end here: nothing is read beyond
     for (uint64_t i64 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i64 < p.n; i64 += stride) {
         const uint32_t i = (uint32_t) i64;
         const uint8_t *key;
@@ -118,17 +137,20 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_insert(GrpParams p)
         const uint32_t h = hashlittle_bytes(key, klen);
         if (p.dest_out) p.dest_out[i] = (uint8_t) fastmod(h, p.fm);
         uint32_t s = (h * 0x9E3779B1u) >> p.slot_shift;
+        const uint32_t place = grp_place(p, i);
+        const unsigned long long mine = ((unsigned long long) h << 32) | place;
         for (uint32_t probes = 0; probes <= p.slot_mask; probes++) { // the table is at most half full
-            uint32_t cur = __hip_atomic_load(p.table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == GRP_EMPTY) {
-                cur = atomicCAS(p.table + s, GRP_EMPTY, i);
-                if (cur == GRP_EMPTY) break; // this record opened the slot
+            unsigned long long cur = __hip_atomic_load(p.table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == GRP_EMPTY64) {
+                cur = atomicCAS(p.table + s, GRP_EMPTY64, mine);
+                if (cur == GRP_EMPTY64) break; // this record opened the slot
             }
-            const uint8_t *okey;
-            uint32_t oklen = 0;
-            if (cur == i || (grp_key(p, cur, okey, oklen) && grp_same_key(key, klen, okey, oklen))) {
-                if (i < cur) atomicMin(p.table + s, i); // the slot keeps the first occurrence
-                break;
+            if ((uint32_t) (cur >> 32) == h) { // same hash: compare the keys in the stream
+                const uint8_t *okey = grp_key_at(p, (uint32_t) cur);
+                if (cur == mine || grp_same_key(key, klen, okey, blob_bytes - (uint64_t) (okey - p.blob))) {
+                    if (mine < cur) atomicMin(p.table + s, mine); // the slot keeps the first occurrence
+                    break;
+                }
             }
             s = (s + 1) & p.slot_mask;
         }
@@ -147,7 +169,7 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_count(GrpParams p)
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; k++) {
         const uint64_t i = t0 + (uint64_t) k * GRP_THREADS + threadIdx.x;
-        const bool first = i < p.n && p.table[p.slot_or_rank[i]] == (uint32_t) i;
+        const bool first = i < p.n && (uint32_t) p.table[p.slot_or_rank[i]] == grp_place(p, i);
         const uint64_t bits = __ballot(first);
         if (lane == 0) p.first_bits[(t0 + (uint64_t) k * GRP_THREADS) / 64 + w] = bits;
         c += (uint32_t) __popcll(bits);
