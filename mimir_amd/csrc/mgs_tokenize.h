@@ -320,14 +320,25 @@ struct TokSink {
             for (int i = 0; i < 4; i++) dst[i] = src[i];
         }
         else {
-            for (uint32_t e = (uint32_t) v_first & 63u; e < 64; e++) out[g + e] = slot[e];
+            store_part(g, (uint32_t) v_first & 63u, 64u);
         }
+    }
+    // bytes [lo, hi) of the group at g: single bytes up to an 8-byte boundary, 8-byte
+    // units, single bytes again
+    __device__ __forceinline__ void store_part(uint64_t g, uint32_t lo, uint32_t hi)
+    {
+        uint32_t e = lo;
+        for (; e < hi && (e & 7u); e++) out[g + e] = slot[e];
+        for (; e + 8 <= hi; e += 8)
+            *reinterpret_cast<uint64_t *>(out + g + e) = *reinterpret_cast<const uint64_t *>(slot + e);
+        for (; e < hi; e++) out[g + e] = slot[e];
     }
     __device__ __forceinline__ void finish()
     {
         if ((uint32_t) v & 7u) *reinterpret_cast<uint64_t *>(slot + ((uint32_t) v & 56u)) = acc;
         const uint64_t g = v & ~(uint64_t) 63;
-        for (uint64_t i = max(g, v_first); i < v; i++) out[i] = slot[(uint32_t) i & 63u];
+        const uint64_t lo = max(g, v_first);
+        if (lo < v) store_part(g, (uint32_t) (lo - g), (uint32_t) (v - g));
     }
 };
 
