@@ -22,14 +22,14 @@
 //             for the chained scan, before the barrier;
 //   reorder   records are copied LDS -> LDS into an image grouped by
 //             destination (`sout`), byte-granular, stable: the first 16 bytes of
-//             every record by two aligned reads and a funnel shift, written as
+//             every record by aligned dword reads and a byte shift, written as
 //             pieces of 8/4/2/1 bytes;
 //   chain     the windowed chained scan of mgs_onesweep16w.h, run by a scan
 //             wave, over byte counts; its first poll is in flight across the
 //             workers' two staging barriers;
 //   store     one trip later, the image is streamed out in 16-byte chunks
 //             aligned to the *global* address of each partition run (aligned
-//             LDS reads + funnel shift, aligned global stores); a wave takes 64
+//             LDS dword reads + byte shift, aligned global stores); a wave takes 64
 //             consecutive chunks of one destination at a time; the partial
 //             chunks at the two ends of a run go out as naturally aligned
 //             pieces.  A run is clipped at the partition's capacity; a clipped
@@ -151,18 +151,13 @@ __device__ __forceinline__ void ov_copy_lds(uint8_t *dst, const uint8_t *src, ui
 }
 
 // 16 bytes of LDS at any alignment.  An LDS access that is not aligned to its
-// size runs at a fifth of the speed, so read the two aligned 16-byte blocks
-// around them and funnel-shift: dword select by bits 2-3 of the offset, then bytes.
-// `base` is 16-byte aligned; up to base[(off & ~15) + 31] is read.
+// size runs at a fifth of the speed, so read the five aligned dwords around them
+// (dword reads at dword addresses are aligned to their size whatever the offset)
+// and shift by bytes.  Up to base[(off & ~3) + 19] is read.
 __device__ __forceinline__ uint4 ov_lds_read16(const uint8_t *base, uint32_t off)
 {
-    const uint4 lo4 = *reinterpret_cast<const uint4 *>(base + (off & ~15u));
-    const uint4 hi4 = *reinterpret_cast<const uint4 *>(base + (off & ~15u) + 16);
-    const bool q2 = (off & 8u) != 0, q1 = (off & 4u) != 0;
-    const uint32_t x0 = q2 ? lo4.z : lo4.x, x1 = q2 ? lo4.w : lo4.y, x2 = q2 ? hi4.x : lo4.z;
-    const uint32_t x3 = q2 ? hi4.y : lo4.w, x4 = q2 ? hi4.z : hi4.x, x5 = q2 ? hi4.w : hi4.y;
-    const uint32_t y0 = q1 ? x1 : x0, y1 = q1 ? x2 : x1, y2 = q1 ? x3 : x2;
-    const uint32_t y3 = q1 ? x4 : x3, y4 = q1 ? x5 : x4;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(base + (off & ~3u));
+    const uint32_t y0 = w[0], y1 = w[1], y2 = w[2], y3 = w[3], y4 = w[4];
     const uint32_t r = off & 3u;
     return make_uint4(__builtin_amdgcn_alignbyte(y1, y0, r), __builtin_amdgcn_alignbyte(y2, y1, r),
                       __builtin_amdgcn_alignbyte(y3, y2, r), __builtin_amdgcn_alignbyte(y4, y3, r));
