@@ -260,6 +260,135 @@ class GpuShuffler:
                 break
 
 
+class CombineGpuShuffler(GpuShuffler):
+    """CombineCollectiveShuffler (src/combinecollectiveshuffler.h) for a combiner
+    declared as one of capi.COMBINE_* instead of a user callback: in a round only
+    the first record of a key is written to its partition, later ones are combined
+    into it (:91-151); a round ends before the first new key that does not fit
+    (:122-127) and forgets its keys (:237); records that stay on this rank go to
+    `out` untouched (:67-83).
+
+    The device call works on a whole round at once, so the records of the current
+    round stay staged until it ends.  When the staging buffer fills first, they
+    are replaced by what the round has made of them so far -- the combined
+    partitions, one after the other.  Inside a partition the order of first
+    occurrence is kept, so partitions, round cuts and counters come out as in the
+    reference."""
+
+    def __init__(self, out, layout, op=capi.COMBINE_SUM_U64, **kw):
+        super().__init__(out, layout, **kw)
+        if layout.val_kind != capi.VAL_FIXED or layout.val_bytes != 8:
+            raise ValueError("a declared combiner needs an 8-byte value")
+        self.op = op
+        # a refill may hold every partition, plus room for new records
+        self.stage_bytes = max(self.stage_bytes, 2 * self.shuffle_size * self.buf_size)
+
+    def open(self):
+        super().open()
+        self._loc_done = 0      # bytes of the round's local stream already handed to `out`
+        self._round_keys = 0    # new keys of the round so far
+        return True
+
+    def write_records(self, blob, rec_off):
+        n = len(rec_off) - 1
+        i = 0
+        while i < n:
+            room = self.stage_bytes - self._stage_used
+            base = int(rec_off[i])
+            j = int(np.searchsorted(rec_off, base + room, side="right")) - 1
+            j = min(j, n, i + self.max_records - (len(self._stage_off) - 1))
+            if j <= i:
+                if self._stage_used == 0:
+                    raise capi.MgsError(capi.ERR_RECORD_SIZE, "record larger than the staging buffer")
+                before = self._stage_used
+                self._drain(final=False)
+                if self._stage_used >= before:
+                    raise capi.MgsError(capi.ERR_RECORD_SIZE, "staging buffer too small for a round")
+                continue
+            nb = int(rec_off[j]) - base
+            self._stage[self._stage_used:self._stage_used + nb] = blob[base:base + nb]
+            self._stage_off.extend((np.asarray(rec_off[i + 1:j + 1], dtype=np.int64) - base
+                                    + self._stage_used).tolist())
+            self._stage_used += nb
+            i = j
+        return True
+
+    def flush(self):
+        """Everything staged goes through the combiner; the round that is still open
+        afterwards sits in the send image (and stays staged, see _drain)."""
+        self._drain(final=True)
+
+    def _drain(self, final):
+        P, bs = self.shuffle_size, self.buf_size
+        while True:
+            n = len(self._stage_off) - 1
+            if n == 0:
+                return
+            blob = torch.from_numpy(self._stage[:self._stage_used]).to(self.dev)
+            d_off = None
+            if not self.layout.fixed_len():
+                d_off = torch.from_numpy(np.asarray(self._stage_off, dtype=np.uint32).view(np.int32)).to(self.dev)
+            r = self.packer.combine(blob, n, self.send_image, start=0, rec_off=d_off,
+                                    local_out=self.local_out, op=self.op)
+            if r.local_bytes > self._loc_done:  # out->write at emit time, :67-83
+                loc = self.local_out[self._loc_done:r.local_bytes].cpu().numpy()
+                self._deliver(loc, self.shuffle_rank)
+                self._loc_done = r.local_bytes
+            self.send_offset[:] = r.send_offset
+            self._round_keys = r.packed_records
+            if r.next < n:  # a new key did not fit: the round ends here (:122-127)
+                if r.next == 0:
+                    raise capi.MgsError(capi.ERR_RECORD_SIZE, "KV size is larger than buf_size")
+                self._end_round()
+                cut = int(self._stage_off[r.next])
+                rest = self._stage_used - cut
+                self._stage[:rest] = self._stage[cut:self._stage_used].copy()
+                self._stage_off = [o - cut for o in self._stage_off[r.next:]]
+                self._stage_used = rest
+                continue
+            if final:
+                return  # the open round is in the send image; its records stay staged
+            # the round goes on but the staging buffer is full: keep what it has made so far
+            img = self.send_image.cpu().numpy()
+            used, offs = 0, [0]
+            for d in range(P):
+                so = int(r.send_offset[d])
+                if so:
+                    part = img[d * bs:d * bs + so]
+                    self._stage[used:used + so] = part
+                    offs.extend((wire_offsets(self.layout, part)[1:].astype(np.int64) + used).tolist())
+                    used += so
+            self._stage_off, self._stage_used, self._loc_done = offs, used, 0
+            return
+
+    def _end_round(self):
+        self.kvcount += self._round_keys
+        self._round_keys = 0
+        self._loc_done = 0
+        self.exchange_kv()
+
+    def exchange_kv(self):
+        # whatever is exchanged ends the round: its keys are forgotten (:237)
+        if self._round_keys:
+            self.kvcount += self._round_keys
+            self._round_keys = 0
+        super().exchange_kv()
+
+    def make_progress(self, issue_new=False):
+        self.flush()
+        self._close_open_round()
+        self.exchange_kv()
+
+    def _close_open_round(self):
+        self._stage_off, self._stage_used, self._loc_done = [0], 0, 0
+
+    def wait(self):
+        """src/collectiveshuffler.h:528-561 after garbage_collection() (:55)."""
+        self.flush()
+        self._close_open_round()
+        super().wait()
+
+
 class _MsgBuf:
     """ShuffleMsgBuf (src/nbcollectiveshuffler.h:22-34): one send image, one
     receive image and the state of the exchange that uses them."""

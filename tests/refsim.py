@@ -26,17 +26,21 @@ def split_records(orc, olay, buf):
     return [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
 
 
-def simulate_shuffle(orc, lay, streams, P, buf_size):
+def simulate_shuffle(orc, lay, streams, P, buf_size, combine_op=None):
     """streams[r] = (blob, rec_off or None, n).  Returns (sinks, stats):
     sinks[r] = list of wire-form records in the order rank r's `out` sees
-    them; stats[r] = dict(kvcount, shuffle_times, send_bytes, recv_bytes)."""
+    them; stats[r] = dict(kvcount, shuffle_times, send_bytes, recv_bytes).
+    With combine_op the rounds are those of CombineCollectiveShuffler."""
     olay = olayout(lay)
     rounds = []  # rounds[r] = list of oracle round dicts
     for r in range(P):
         blob, offs, n = streams[r]
         rs, start = [], 0
         while True:
-            rd = orc.pack_round(olay, blob, offs, n, start, P, r, buf_size)
+            if combine_op is None:
+                rd = orc.pack_round(olay, blob, offs, n, start, P, r, buf_size)
+            else:
+                rd = orc.combine_round(olay, blob, offs, n, start, P, r, buf_size, combine_op)
             rs.append(rd)
             start = rd["next"]
             if start >= n:
@@ -112,6 +116,27 @@ class OraclePacker:
         nxt = self.orc.L.mo_pack_more(
             C.byref(self.olay), b.ctypes.data, offs.ctypes.data if offs is not None else None,
             self.olay.fixed_len() or 0, n, start, self.P, self.rank, self.buf_size,
+            img.ctypes.data, so.ctypes.data, loc.ctypes.data, len(loc),
+            C.byref(lb), C.byref(lr), C.byref(pr))
+        if nxt == O.U64_MAX:
+            raise ValueError("oracle packer: bad record")
+        r = _Round()
+        r.next, r.send_offset = nxt, so
+        r.packed_records, r.local_records, r.local_bytes = pr.value, lr.value, lb.value
+        return r
+
+    def combine(self, blob, n, send_image, start=0, rec_off=None, local_out=None, op=0):
+        b = blob.numpy()
+        offs = None
+        if rec_off is not None:
+            offs = np.ascontiguousarray(rec_off.numpy().view(np.uint32).astype(np.uint64))
+        so = np.zeros(self.P, dtype=np.int64)
+        img = send_image.numpy()
+        loc = local_out.numpy()
+        lb, lr, pr = C.c_int64(), C.c_uint64(), C.c_uint64()
+        nxt = self.orc.L.mo_combine_round(
+            C.byref(self.olay), b.ctypes.data, offs.ctypes.data if offs is not None else None,
+            self.olay.fixed_len() or 0, n, start, self.P, self.rank, self.buf_size, op,
             img.ctypes.data, so.ctypes.data, loc.ctypes.data, len(loc),
             C.byref(lb), C.byref(lr), C.byref(pr))
         if nxt == O.U64_MAX:

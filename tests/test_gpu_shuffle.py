@@ -26,3 +26,12 @@ def test_gpu_shuffle_default_geometry(oracle):
 def test_gpu_nonblocking_shuffle(oracle, P, kind):
     """NBCollectiveShuffler mirror over the real pack path."""
     run_nb_case(oracle, P, kind, use_gpu=True)
+
+
+@pytest.mark.parametrize("P,comm", [(2, 4096), (3, 6144)])
+def test_gpu_combiner_shuffle(oracle, P, comm):
+    """CombineGpuShuffler over the device combiner (mgs_combine_device): sinks, order and
+    counters equal the oracle simulation of CombineCollectiveShuffler with a sum."""
+    from mimir_amd import capi
+    counts = [0 if r == 1 else 9000 * (r + 1) + 37 for r in range(P)]
+    run_case(oracle, P, "words", comm=comm, use_gpu=True, counts=counts, combine_op=capi.COMBINE_SUM_U64)

@@ -45,18 +45,22 @@ def counts_for(P):
     return [0 if r == 1 else 4000 * (r + 1) + 37 for r in range(P)]
 
 
-def _worker(rank, P, port, kind, comm, outdir, use_gpu, counts):
+def _worker(rank, P, port, kind, comm, outdir, use_gpu, counts, combine_op=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=P)
     try:
-        from mimir_amd.shuffler import GpuShuffler, ListSink
+        from mimir_amd.shuffler import CombineGpuShuffler, GpuShuffler, ListSink
         n = counts[rank]
         blob, offs, lay = make_stream(kind, rank, n)
         sink = ListSink()
         factory = None if use_gpu else refsim.OraclePacker
-        sh = GpuShuffler(sink, lay, comm_buf_size=comm, stage_bytes=1 << 16,
-                         packer_factory=factory)
+        if combine_op is None:
+            sh = GpuShuffler(sink, lay, comm_buf_size=comm, stage_bytes=1 << 16,
+                             packer_factory=factory)
+        else:
+            sh = CombineGpuShuffler(sink, lay, op=combine_op, comm_buf_size=comm, stage_bytes=1 << 16,
+                                    packer_factory=factory)
         sh.open()
         if offs is None:
             offs = datagen.fixed_offsets(n, lay.fixed_len())
@@ -74,17 +78,17 @@ def _worker(rank, P, port, kind, comm, outdir, use_gpu, counts):
         dist.destroy_process_group()
 
 
-def run_case(oracle, P, kind, comm, use_gpu=False, min_rounds=3, counts=None):
+def run_case(oracle, P, kind, comm, use_gpu=False, min_rounds=3, counts=None, combine_op=None):
     counts = counts or counts_for(P)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(P, _free_port(), kind, comm, d, use_gpu, counts), nprocs=P, join=True)
+        mp.spawn(_worker, args=(P, _free_port(), kind, comm, d, use_gpu, counts, combine_op), nprocs=P, join=True)
         got = [pickle.load(open(os.path.join(d, f"rank{r}.pkl"), "rb")) for r in range(P)]
     streams, lay = [], None
     for r in range(P):
         blob, offs, lay = make_stream(kind, r, counts[r])
         streams.append((blob, offs, counts[r]))
     buf_size = capi.geometry(comm, P)[0]
-    sinks, stats = refsim.simulate_shuffle(oracle, lay, streams, P, buf_size)
+    sinks, stats = refsim.simulate_shuffle(oracle, lay, streams, P, buf_size, combine_op=combine_op)
     assert max(s["shuffle_times"] for s in stats) >= min_rounds, "case too small to cut rounds"
     for r in range(P):
         assert got[r]["records"] == sinks[r], f"rank {r}: sink contents/order differ"
@@ -92,12 +96,21 @@ def run_case(oracle, P, kind, comm, use_gpu=False, min_rounds=3, counts=None):
             assert got[r][k] == stats[r][k], (r, k, got[r][k], stats[r][k])
     # every record ends on the rank its key hashes to, exactly once
     total = sum(len(s) for s in sinks)
-    assert total == sum(counts)
+    assert total == sum(counts) or combine_op is not None
 
 
 @pytest.mark.parametrize("P,kind", [(2, "u64"), (2, "words"), (3, "join"), (4, "oct")])
 def test_shuffle_matches_reference_simulation(oracle, P, kind):
     run_case(oracle, P, kind, comm=16384)
+
+
+@pytest.mark.parametrize("P,comm", [(2, 4096), (3, 6144), (4, 4096)])
+def test_combiner_shuffle_matches_reference_simulation(oracle, P, comm):
+    """CombineGpuShuffler: rounds of unique keys with summed counts, cut where a new key
+    does not fit, while records arrive in staging batches that end inside rounds and
+    the staging buffer has to be refilled with the round's partitions."""
+    counts = [0 if r == 1 else 9000 * (r + 1) + 37 for r in range(P)]
+    run_case(oracle, P, "words", comm=comm, counts=counts, combine_op=capi.COMBINE_SUM_U64)
 
 
 def test_exchange_layout_two_ranks(oracle):
