@@ -337,7 +337,18 @@ int mgs_combine_device(mgs_handle *h, const void *d_records, const uint32_t *d_r
  *                     in place on the GPU (for RCCL / GPU-aware MPI).
  *   mgs_stager_round_done
  *                     the exchange is over: send_offset[*] = 0 (:657).
- *   mgs_stager_pending records staged but not packed yet. */
+ *   mgs_stager_pending records staged but not packed yet.
+ *   mgs_stager_set_combine
+ *                     the combiner shuffler (src/combinecollectiveshuffler.h:
+ *                     63-180) with a declared operation (mgs_combine_op; -1 =
+ *                     off): mgs_stager_pack then runs mgs_combine_device over
+ *                     the current round, whose records stay staged until it
+ *                     ends (a partition cut, or an exchange asked for by the
+ *                     caller); when the staging buffer fills first they are
+ *                     replaced by the round's combined partitions.  The
+ *                     staging buffer must hold two send images.  out->
+ *                     local_bytes / packed_records of a pack are what that
+ *                     call added. */
 typedef struct mgs_stager mgs_stager;
 int mgs_stager_create(mgs_handle *h, int64_t stage_bytes, mgs_stager **out);
 void mgs_stager_destroy(mgs_stager *s);
@@ -352,6 +363,7 @@ int mgs_stager_send_image_host(mgs_stager *s, const void **host_image,
 int mgs_stager_send_image_device(mgs_stager *s, void **d_image,
                                  const int64_t **send_offset);
 int mgs_stager_round_done(mgs_stager *s);
+int mgs_stager_set_combine(mgs_stager *s, int op);
 
 /* Device time of the dominant kernel of the last completed pack call (the
  * one-sweep kernel, or the generic path's scatter kernel), from HIP events

@@ -154,12 +154,15 @@ class GpuShuffler : public Writable<KeyType, ValType> {
   public:
     // Same parameter list as CollectiveShuffler (src/collectiveshuffler.h:25-31)
     // with the communicator replaced by an Exchange; `h` (HashBucket) is unused
-    // because load balancing is not supported.
+    // because load balancing is not supported.  combine_op >= 0 (mgs_combine_op)
+    // makes it the CombineCollectiveShuffler (src/combinecollectiveshuffler.h) for
+    // a combiner that is one of the declared operations instead of a callback.
     GpuShuffler(Exchange *comm, Writable<KeyType, ValType> *out,
                 int (*user_hash)(KeyType *key, ValType *val, int npartition), int keycount,
                 int valcount, bool split_hint = false, void *h = NULL,
-                int64_t comm_buf_size = 0, int device = 0)
-        : comm(comm), out(out), keycount(keycount), valcount(valcount), device(device)
+                int64_t comm_buf_size = 0, int device = 0, int combine_op = -1)
+        : comm(comm), out(out), keycount(keycount), valcount(valcount), device(device),
+          combine_op(combine_op)
     {
         (void) split_hint;
         (void) h;
@@ -198,10 +201,16 @@ class GpuShuffler : public Writable<KeyType, ValType> {
         d.layout.val_count = valcount;
         d.buf_size = buf_size;
         d.device = device;
-        const int64_t stage = env_size("MIMIR_GPU_STAGE_SIZE", this->comm_buf_size);
+        int64_t stage = env_size("MIMIR_GPU_STAGE_SIZE", this->comm_buf_size);
+        // with a combiner the current round stays staged: room for a send image of combined
+        // records plus one of new ones
+        if (combine_op >= 0 && stage < 2 * buf_size * shuffle_size) stage = 2 * buf_size * shuffle_size;
         d.max_records = (uint64_t) stage; // one byte per record is the densest possible stream
         if (mgs_create(&d, &handle) != MGS_OK) fail(mgs_last_error(NULL));
         if (mgs_stager_create(handle, stage, &stager) != MGS_OK) fail(mgs_stager_last_error(NULL));
+        // CombineCollectiveShuffler with the user's callback declared as an operation
+        if (combine_op >= 0 && mgs_stager_set_combine(stager, combine_op) != MGS_OK)
+            fail(mgs_stager_last_error(stager));
         recv_buffer.resize((size_t) buf_size * (size_t) shuffle_size);
         send_count.assign((size_t) shuffle_size, 0);
         recv_count.assign((size_t) shuffle_size, 0);
@@ -386,7 +395,7 @@ class GpuShuffler : public Writable<KeyType, ValType> {
 
     Exchange *comm;
     Writable<KeyType, ValType> *out;
-    int keycount, valcount, device;
+    int keycount, valcount, device, combine_op;
     int shuffle_rank, shuffle_size, shuffle_times;
     int done_flag, done_count;
     uint64_t kvcount;

@@ -36,6 +36,12 @@ struct mgs_stager {
     uint64_t cursor = 0; // first staged record not packed yet
     bool uploaded = false;
     int64_t send_offset[MGS_MAX_RANKS];
+    // combiner mode (mgs_stager_set_combine): the current round's records stay staged
+    int combine_op = -1;
+    int64_t loc_done = 0;        // bytes of the round's local stream already handed out
+    uint64_t round_keys = 0;     // new keys of the round reported so far
+    bool cut_pending = false;    // the last pack ended a round: what is staged belongs to the next
+    bool want_refill = false;    // a put found no room
     hipStream_t stream = nullptr;
     std::string err;
 };
@@ -69,7 +75,132 @@ int fixed_len(const mgs_layout &l)
         }                                                                        \
     } while (0)
 
+// Combiner mode.  mgs_combine_device works on a whole round, records arrive in
+// batches: the current round's records stay staged and the round is recombined
+// from its start.  A cut ends the round: the records before it leave the staging
+// buffer.  When the buffer is full and the round goes on, the staged records are
+// replaced by what the round has made of them -- its combined partitions one
+// after the other (inside a partition the order of first occurrence is kept, so
+// partitions, cuts and counters stay those of
+// src/combinecollectiveshuffler.h:63-180).  out->local_bytes / packed_records
+// are what this call added.
+static int stager_record_len(const mgs_stager *s, const uint8_t *p, int64_t room)
+{
+    const mgs_layout &l = s->desc.layout;
+    int64_t k = 0;
+    if (l.key_kind == MGS_KEY_FIXED) {
+        k = l.key_bytes;
+    }
+    else {
+        for (int c = 0; c < (l.key_count > 0 ? l.key_count : 1); c++) {
+            while (k < room && p[k] != 0) k++;
+            k++;
+        }
+    }
+    return (k + 8 <= room) ? (int) (k + 8) : -1;
+}
+
+static int stager_pack_combine(mgs_stager *s, mgs_round *out, int *drained)
+{
+    const int P = s->desc.nranks;
+    if (s->nrec == 0) {
+        for (int b = 0; b < P; b++) out->send_offset[b] = s->send_offset[b];
+        *drained = 1;
+        return MGS_OK;
+    }
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    struct Restore {
+        int p;
+        ~Restore() { if (p >= 0) (void) hipSetDevice(p); }
+    } restore{prev};
+    STG_HIP(s, hipSetDevice(s->desc.device));
+    STG_HIP(s, hipMemcpyAsync(s->d_stage, s->h_stage, (size_t) s->used, hipMemcpyHostToDevice, s->stream));
+    if (!s->fixed)
+        STG_HIP(s, hipMemcpyAsync(s->d_off, s->h_off, (s->nrec + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    int rc = mgs_combine_device(s->h, s->d_stage, s->fixed ? nullptr : s->d_off, s->nrec, 0, s->combine_op, s->d_image,
+                                s->desc.rank >= 0 ? s->d_local : nullptr, s->cap, s->stream, out);
+    if (rc != MGS_OK) {
+        s->err = mgs_last_error(s->h);
+        return rc;
+    }
+    const int64_t new_local = out->local_bytes - s->loc_done;
+    if (new_local > 0) {
+        STG_HIP(s, hipMemcpyAsync(s->h_local, s->d_local + s->loc_done, (size_t) new_local, hipMemcpyDeviceToHost, s->stream));
+        STG_HIP(s, hipStreamSynchronize(s->stream));
+    }
+    s->loc_done = out->local_bytes;
+    out->local_bytes = new_local > 0 ? new_local : 0;
+    const uint64_t keys = out->packed_records;
+    out->packed_records = keys > s->round_keys ? keys - s->round_keys : 0;
+    s->round_keys = keys;
+    for (int b = 0; b < P; b++) s->send_offset[b] = out->send_offset[b];
+    if (out->next < s->nrec) { // a new key did not fit: the round ends before it
+        if (out->next == 0) {
+            s->err = "KV size is larger than buf_size";
+            return MGS_ERR_RECORD_SIZE;
+        }
+        const int64_t cut = s->fixed ? (int64_t) out->next * fixed_len(s->desc.layout) : (int64_t) s->h_off[out->next];
+        memmove(s->h_stage, s->h_stage + cut, (size_t) (s->used - cut));
+        if (!s->fixed)
+            for (uint64_t i = out->next; i <= s->nrec; i++) s->h_off[i - out->next] = s->h_off[i] - (uint32_t) cut;
+        s->used -= cut;
+        s->nrec -= out->next;
+        s->loc_done = 0;
+        s->round_keys = 0;
+        s->cut_pending = true;
+        *drained = 0;
+        return MGS_OK;
+    }
+    if (s->want_refill) { // the buffer is full and the round goes on: keep what it has made so far
+        int64_t used = 0;
+        uint64_t nrec = 0;
+        for (int b = 0; b < P; b++) {
+            if (s->send_offset[b] > 0)
+                STG_HIP(s, hipMemcpyAsync(s->h_stage + used, s->d_image + (size_t) b * s->desc.buf_size,
+                                          (size_t) s->send_offset[b], hipMemcpyDeviceToHost, s->stream));
+            used += s->send_offset[b];
+        }
+        STG_HIP(s, hipStreamSynchronize(s->stream));
+        if (!s->fixed) {
+            int64_t pos = 0;
+            while (pos < used) {
+                const int len = stager_record_len(s, s->h_stage + pos, used - pos);
+                if (len <= 0 || nrec >= s->max_rec) {
+                    s->err = "combined partitions do not parse";
+                    return MGS_ERR_STATE;
+                }
+                pos += len;
+                s->h_off[++nrec] = (uint32_t) pos;
+            }
+        }
+        else {
+            nrec = (uint64_t) used / (uint64_t) fixed_len(s->desc.layout);
+        }
+        s->used = used;
+        s->nrec = nrec;
+        s->loc_done = 0;
+        s->want_refill = false;
+    }
+    *drained = 1;
+    return MGS_OK;
+}
+
 extern "C" {
+
+// Switch the stager to the combiner shuffler (op: mgs_combine_op, or -1 for the
+// plain one).  The staging buffer must hold two send images: one for a refill
+// with the round's partitions, one for new records.  Call before the first put.
+int mgs_stager_set_combine(mgs_stager *s, int op)
+{
+    if (!s) return MGS_ERR_ARG;
+    if (op >= 0 && (s->cap < 2 * (int64_t) s->desc.nranks * s->desc.buf_size || s->nrec != 0)) {
+        s->err = "mgs_stager_set_combine: staging buffer below two send images, or records already staged";
+        return MGS_ERR_ARG;
+    }
+    s->combine_op = op;
+    return MGS_OK;
+}
 
 const char *mgs_stager_last_error(const mgs_stager *s)
 {
@@ -152,7 +283,10 @@ int mgs_stager_put(mgs_stager *s, const void *key, uint32_t klen, const void *va
                       (long long) len, (long long) s->cap);
         return MGS_ERR_RECORD_SIZE;
     }
-    if (s->uploaded || s->nrec >= s->max_rec || s->used + len > s->cap) return 1;
+    if (s->uploaded || s->nrec >= s->max_rec || s->used + len > s->cap) {
+        s->want_refill = true;
+        return 1;
+    }
     if (klen) memcpy(s->h_stage + s->used, key, klen);
     if (vlen) memcpy(s->h_stage + s->used + klen, val, vlen);
     s->used += len;
@@ -175,6 +309,7 @@ int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records, i
     if (!s || !out || !drained) return MGS_ERR_ARG;
     memset(out, 0, sizeof(*out));
     if (local_records) *local_records = s->h_local;
+    if (s->combine_op >= 0) return stager_pack_combine(s, out, drained);
     if (s->cursor >= s->nrec) {
         for (int b = 0; b < s->desc.nranks; b++) out->send_offset[b] = s->send_offset[b];
         out->next = s->cursor;
@@ -278,6 +413,18 @@ int mgs_stager_round_done(mgs_stager *s)
 {
     if (!s) return MGS_ERR_ARG;
     memset(s->send_offset, 0, sizeof(s->send_offset));
+    if (s->combine_op >= 0) {
+        // the exchange forgets the round's keys (garbage_collection, src/combinecollectiveshuffler.h:237):
+        // after a cut the staged records already belong to the next round, otherwise the
+        // round that was open is over and its records go
+        if (!s->cut_pending) {
+            s->nrec = 0;
+            s->used = 0;
+            s->loc_done = 0;
+            s->round_keys = 0;
+        }
+        s->cut_pending = false;
+    }
     return MGS_OK;
 }
 

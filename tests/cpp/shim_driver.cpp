@@ -4,7 +4,8 @@
 // all-to-all standing in for MPI.  Dumps what each rank's `out` received.
 //
 //   shim_driver <kind> <P> <comm_bytes> <stage_bytes> <indir> <outdir> [keycount] [nb]
-//   kind: u64 | words | oct | join;  nb: NBGpuShuffler over non-blocking exchanges
+//   kind: u64 | words | oct | join;  nb: NBGpuShuffler over non-blocking exchanges;
+//   sum (in place of nb): GpuShuffler as the combiner shuffler with MGS_COMBINE_SUM_U64
 #include <pthread.h>
 
 #include <map>
@@ -192,6 +193,7 @@ class Tagged : public Sh {
 };
 
 static bool g_nb = false;
+static int g_combine = -1;
 
 template <typename K, typename V, typename Feed>
 static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const std::string &indir,
@@ -213,7 +215,7 @@ static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const s
     }
     else {
         Tagged<GpuShuffler<K, V>, K, V> *t =
-            new Tagged<GpuShuffler<K, V>, K, V>(&ex, &sink, NULL, keycount, 1, false, NULL, comm, 0);
+            new Tagged<GpuShuffler<K, V>, K, V>(&ex, &sink, NULL, keycount, 1, false, NULL, comm, 0, g_combine);
         t->sink = &sink;
         c = t;
     }
@@ -244,6 +246,7 @@ int main(int argc, char **argv)
     const std::string indir = argv[5], outdir = argv[6];
     const int keycount = argc > 7 ? atoi(argv[7]) : 1;
     g_nb = argc > 8 && std::string(argv[8]) == "nb";
+    if (argc > 8 && std::string(argv[8]) == "sum") g_combine = MGS_COMBINE_SUM_U64;
     setenv("MIMIR_GPU_STAGE_SIZE", std::to_string(stage).c_str(), 1);
     Shared sh;
     sh.P = P;

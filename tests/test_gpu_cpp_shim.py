@@ -92,3 +92,34 @@ def test_cpp_nonblocking_shim_matches_reference(oracle, kind, P, keycount):
             assert 2 <= int(buffers) <= 5
             # every data round of the busiest rank is an exchange, plus at least the vote
             assert int(times) >= max(len(x) for x in rounds) + 1
+
+
+@pytest.mark.parametrize("P,comm", [(2, 4096), (3, 6144), (4, 4096)])
+def test_cpp_combiner_shim_matches_reference(oracle, P, comm):
+    """GpuShuffler<char*, uint64_t> with combine_op = MGS_COMBINE_SUM_U64 (the mirror of
+    CombineCollectiveShuffler with wordcount's combiner): what every rank's `out` receives,
+    in order, and the counters equal the oracle simulation with combining rounds."""
+    assert os.path.exists(DRIVER), "tests/cpp/shim_driver not built (__graft_entry__.build)"
+    counts = [0 if r == 1 else 9000 * (r + 1) + 37 for r in range(P)]
+    streams, lay = [], None
+    with tempfile.TemporaryDirectory() as d:
+        ind, outd = os.path.join(d, "in"), os.path.join(d, "out")
+        os.makedirs(ind)
+        os.makedirs(outd)
+        for r in range(P):
+            blob, offs, lay = make_stream("words", r, counts[r])
+            streams.append((blob, offs, counts[r]))
+            blob.tofile(os.path.join(ind, f"rank{r}.blob"))
+            np.asarray(offs, dtype=np.uint64).tofile(os.path.join(ind, f"rank{r}.off"))
+        subprocess.run([DRIVER, "words", str(P), str(comm), str(40000), ind, outd, "1", "sum"],
+                       check=True, timeout=240)
+        buf_size = capi.geometry(comm, P)[0]
+        sinks, stats = refsim.simulate_shuffle(oracle, lay, streams, P, buf_size, combine_op=capi.COMBINE_SUM_U64)
+        assert max(s["shuffle_times"] for s in stats) >= 3
+        for r in range(P):
+            data = np.fromfile(os.path.join(outd, f"rank{r}.out"), dtype=np.uint8).tobytes()
+            off = np.fromfile(os.path.join(outd, f"rank{r}.outoff"), dtype=np.uint64)
+            got = [data[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+            assert got == sinks[r], f"rank {r}: sink differs"
+            kv, times, _ = open(os.path.join(outd, f"rank{r}.txt")).read().split()
+            assert int(kv) == stats[r]["kvcount"] and int(times) == stats[r]["shuffle_times"]
