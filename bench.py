@@ -123,11 +123,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if distributed:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank
+    # MGS_BENCH_BACKEND=gloo is the rehearsal mode for boxes with fewer GPUs than
+    # ranks: ranks share the devices round-robin and the partitions travel through
+    # host memory.  Its numbers say nothing about xGMI and are labelled as such.
+    backend = os.environ.get("MGS_BENCH_BACKEND", "nccl")
+    dev = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
     torch.cuda.set_device(dev)
+    if distributed and backend == "gloo":
+        dist.init_process_group("gloo")
+    elif distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     n = int(args.records)
     P = 8 if not distributed else world
@@ -181,9 +186,14 @@ def main():
         if r.next != n:
             raise RuntimeError(f"round cut at {r.next}: partition capacity too small")
         kernel_ms.append(pk.last_kernel_ms())
-        if distributed:
+        if distributed and backend == "gloo":
+            recv_host = torch.empty(recv.shape, dtype=torch.uint8)
+            _, _, got = exchange_round(image.cpu(), r.send_offset, buf_size, recv_host)
+            recv[:got].copy_(recv_host[:got])
+        elif distributed:
             exchange_round(image, r.send_offset, buf_size, recv)
-            sent_max = max(sent_max, int(r.send_offset.max()))
+        if distributed:
+            sent_max = max(sent_max, int(max(r.send_offset)))
         return r
 
     def barrier():
@@ -202,7 +212,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device="cpu" if backend == "gloo" else f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -230,7 +241,9 @@ def main():
         "GBps_algorithmic": value * algo_bytes / n / 1e9,
         "config": {
             "workload": (what + f", hash-partition+pack into {P} destination partitions"
-                         + (", then RCCL all-to-all" if distributed else "")),
+                         + ((", then RCCL all-to-all" if backend == "nccl" else
+                             ", then a gloo exchange through host memory (rehearsal, not xGMI)")
+                            if distributed else "")),
             "records_per_gpu": n, "record_bytes": total_bytes / n, "partitions": P,
             "local_bypass": distributed, "kernel_variant": kname,
             "rounds": "one round holds the batch",
