@@ -76,24 +76,38 @@ __device__ __forceinline__ uint64_t ov_offset(const OvParams &q, uint64_t i)
     return q.rec_off ? (uint64_t) q.rec_off[q.first + i] : (q.first + i) * (uint64_t) q.fixed_len;
 }
 
-// lookup3 hashlittle (src/hash.cpp:152-400, initval 0) over klen >= 1 bytes at s (LDS,
-// any alignment; up to 11 bytes past the key may be read and are masked off).
-__device__ __forceinline__ uint32_t ov_hash_lds(const uint8_t *s, uint32_t klen)
+// 12 bytes of LDS at any alignment.  An LDS access that is not aligned to its size
+// runs at a fifth of the speed, so read the four aligned dwords around them and
+// shift by bytes.  Up to base[(off & ~3) + 15] is read.
+__device__ __forceinline__ void ov_lds_read12(const uint8_t *base, uint32_t off, uint32_t &w0, uint32_t &w1,
+                                              uint32_t &w2)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(base + (off & ~3u));
+    const uint32_t y0 = w[0], y1 = w[1], y2 = w[2], y3 = w[3];
+    const uint32_t r = off & 3u;
+    w0 = __builtin_amdgcn_alignbyte(y1, y0, r);
+    w1 = __builtin_amdgcn_alignbyte(y2, y1, r);
+    w2 = __builtin_amdgcn_alignbyte(y3, y2, r);
+}
+
+// lookup3 hashlittle (src/hash.cpp:152-400, initval 0) over klen >= 1 bytes at base + off
+// (LDS, any alignment; up to 14 bytes past the key may be read and are masked off).
+__device__ __forceinline__ uint32_t ov_hash_lds(const uint8_t *base, uint32_t off, uint32_t klen)
 {
     uint32_t a, b, c;
     a = b = c = 0xdeadbeefu + klen;
     uint32_t rem = klen;
+    uint32_t w0, w1, w2;
     while (rem > 12) {
-        a += reinterpret_cast<const OvU32 *>(s)->v;
-        b += reinterpret_cast<const OvU32 *>(s + 4)->v;
-        c += reinterpret_cast<const OvU32 *>(s + 8)->v;
+        ov_lds_read12(base, off, w0, w1, w2);
+        a += w0;
+        b += w1;
+        c += w2;
         MGS_MIX(a, b, c);
-        s += 12;
+        off += 12;
         rem -= 12;
     }
-    const uint32_t w0 = reinterpret_cast<const OvU32 *>(s)->v;
-    const uint32_t w1 = reinterpret_cast<const OvU32 *>(s + 4)->v;
-    const uint32_t w2 = reinterpret_cast<const OvU32 *>(s + 8)->v;
+    ov_lds_read12(base, off, w0, w1, w2);
     // word j keeps its first clamp(rem - 4j, 0, 4) bytes
     const uint32_t m0 = rem >= 4 ? 0xFFFFFFFFu : ((1u << (8 * rem)) - 1u);
     const uint32_t m1 = rem >= 8 ? 0xFFFFFFFFu : (rem > 4 ? ((1u << (8 * (rem - 4))) - 1u) : 0u);
@@ -376,50 +390,58 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
             const unsigned long long G = gaddr2[pr * OS_MAXP + b];
             const uint32_t nb = nbytes2[pr * OS_MAXP + b];
             const uint32_t ds = dstart2[pr * OS_MAXP + b]; // image byte of global byte G
-            const uint32_t nch = (uint32_t) (((G & 15ull) + nb + 15ull) >> 4);
-            const uint32_t cb = (u - u0) * 64u + (uint32_t) lane;
-            if (cb >= nch) continue;
-            const unsigned long long g0 = (G & ~15ull) + ((unsigned long long) cb << 4);
-            if (g0 >= G && g0 + 16 <= G + nb) {
-                const uint4 val = ov_lds_read16(sout, ds + (uint32_t) (g0 - G));
+            const uint32_t a = (uint32_t) G & 15u;         // the run starts `a` bytes into its first chunk
+            const uint32_t off = ((u - u0) * 64u + (uint32_t) lane) << 4; // this lane's chunk, from the aligned start
+            // whole chunks only; the partial chunks at the two ends of the runs follow below
+            if (off >= a && off + 16u <= a + nb) {
+                const uint4 val = ov_lds_read16(sout, ds + off - a);
                 if (VAR & OSV_NT_STORE) // timing experiment: no global store
                     asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));
                 else
-                    *reinterpret_cast<uint4 *>(g0) = val;
+                    *reinterpret_cast<uint4 *>((G - a) + off) = val;
             }
-            else if (!(VAR & OSV_NT_LOAD)) { // (timing experiment: partial chunks skipped)
-                // partial chunk at an end of the run: naturally aligned pieces, growing
-                // from the first byte, then shrinking towards the last
-                const uint8_t *src0 = sout + ds;
-                unsigned long long ga = g0 > G ? g0 : G;
-                const unsigned long long gb = g0 + 16 < G + nb ? g0 + 16 : G + nb;
-                if ((ga & 1) && ga + 1 <= gb) {
-                    *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
-                    ga += 1;
-                }
-                if ((ga & 2) && ga + 2 <= gb) {
-                    *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
-                    ga += 2;
-                }
-                if ((ga & 4) && ga + 4 <= gb) {
-                    *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
-                    ga += 4;
-                }
-                if (ga + 8 <= gb) {
-                    *reinterpret_cast<unsigned long long *>(ga) =
-                        reinterpret_cast<const OvU64 *>(src0 + (ga - G))->v;
-                    ga += 8;
-                }
-                if (ga + 4 <= gb) {
-                    *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
-                    ga += 4;
-                }
-                if (ga + 2 <= gb) {
-                    *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
-                    ga += 2;
-                }
-                if (ga + 1 <= gb) *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
+        }
+        // The partial chunks (at most two per destination): one wave, lane = (destination,
+        // end), so that the divergent byte work runs once per tile and not once per unit.
+        if (w != WORKERS - 1 || (VAR & OSV_NT_LOAD)) return; // (NT_LOAD: timing experiment without them)
+        for (uint32_t it = (uint32_t) lane; it < 2u * P; it += 64u) {
+            const uint32_t b = it >> 1;
+            const unsigned long long G = gaddr2[pr * OS_MAXP + b];
+            const uint32_t nb = nbytes2[pr * OS_MAXP + b];
+            if (nb == 0) continue;
+            const uint32_t nch = (uint32_t) (((G & 15ull) + nb + 15ull) >> 4);
+            if ((it & 1u) && nch == 1) continue; // the only chunk is taken as the first
+            const unsigned long long g0 = (G & ~15ull) + ((it & 1u) ? (unsigned long long) (nch - 1u) << 4 : 0ull);
+            if (g0 >= G && g0 + 16 <= G + nb) continue; // a whole chunk: stored above
+            // naturally aligned pieces, growing from the first byte, then shrinking towards the last
+            const uint8_t *src0 = sout + dstart2[pr * OS_MAXP + b];
+            unsigned long long ga = g0 > G ? g0 : G;
+            const unsigned long long gb = g0 + 16 < G + nb ? g0 + 16 : G + nb;
+            if ((ga & 1) && ga + 1 <= gb) {
+                *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
+                ga += 1;
             }
+            if ((ga & 2) && ga + 2 <= gb) {
+                *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
+                ga += 2;
+            }
+            if ((ga & 4) && ga + 4 <= gb) {
+                *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
+                ga += 4;
+            }
+            if (ga + 8 <= gb) {
+                *reinterpret_cast<unsigned long long *>(ga) = reinterpret_cast<const OvU64 *>(src0 + (ga - G))->v;
+                ga += 8;
+            }
+            if (ga + 4 <= gb) {
+                *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
+                ga += 4;
+            }
+            if (ga + 2 <= gb) {
+                *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
+                ga += 2;
+            }
+            if (ga + 1 <= gb) *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
         }
     };
 
@@ -477,9 +499,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
             }
             if (ok && klen <= 12) {
                 // the whole key is lookup3's tail: three words, masked to the key's bytes
-                const uint32_t w0 = reinterpret_cast<const OvU32 *>(r)->v;
-                const uint32_t w1 = reinterpret_cast<const OvU32 *>(r + 4)->v;
-                const uint32_t w2 = reinterpret_cast<const OvU32 *>(r + 8)->v;
+                uint32_t w0, w1, w2;
+                ov_lds_read12(sin, lo[k], w0, w1, w2);
                 const uint32_t m0 = klen >= 4 ? 0xFFFFFFFFu : ((1u << (8 * klen)) - 1u);
                 const uint32_t m1 = klen >= 8 ? 0xFFFFFFFFu : (klen > 4 ? ((1u << (8 * (klen - 4))) - 1u) : 0u);
                 const uint32_t m2 = klen >= 12 ? 0xFFFFFFFFu : (klen > 8 ? ((1u << (8 * (klen - 8))) - 1u) : 0u);
@@ -498,7 +519,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
             }
             else if (ok) {
                 if (LM == 1) ok = r[klen - 1] == 0;
-                h[k] = ov_hash_lds(r, klen);
+                h[k] = ov_hash_lds(sin, lo[k], klen);
             }
             if (!ok) {
                 raise_error(p.ctrl, MGS_ERR_MALFORMED);
