@@ -207,7 +207,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
     const OsParams &p = q.os;
     constexpr int WORKERS = THREADS / 64 - 1, WT = WORKERS * 64, T = WT * K;
     constexpr int CPT = (OV_IN_BYTES / 16 + WT - 1) / WT; // 16-byte chunks per worker thread
-    __shared__ __attribute__((aligned(16))) uint8_t sin[OV_IN_BYTES + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sin[OV_IN_BYTES + 32]; // reads run up to 19 bytes past a record
     __shared__ __attribute__((aligned(16))) uint8_t sout[OV_IN_BYTES + 16];
     __shared__ uint32_t wcnt[2 * WORKERS * OS_MAXP]; // bytes per (wave, dest), two tiles
     __shared__ uint32_t wslot[WORKERS * OS_MAXP];    // first image byte of (wave, dest)
@@ -603,19 +603,20 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
         const uint32_t first_byte = wave_incl_scan_u32(tot, lane) - tot;
         wslot[w * OS_MAXP + lane] = first_byte + below;
         if (w == 0) dstart2[par * OS_MAXP + lane] = first_byte;
+        // bytes of the next tile (its offsets arrived during the last trip): in flight
+        // during the store and the reorder
+        uint4 ch[CPT];
+        if (next < p.ntiles) fetch_chunks(fn.base + fn.s, fn.base + fn.e, ch);
         if (have_prev) store_image(par ^ 1);
         OV_PHASE(3)
         __syncthreads(); // B: the image is free
         OV_PHASE(4)
         const uint32_t next2 = misc[1];
 
-        // bytes of the next tile (its offsets arrived during the last trip) and offsets of
-        // the tile after it: in flight during the reorder
-        uint4 ch[CPT];
+        // offsets of the tile after the next: in flight during the reorder
         Offsets fn2;
         fn2.base = 0;
         fn2.s = fn2.e = 0;
-        if (next < p.ntiles) fetch_chunks(fn.base + fn.s, fn.base + fn.e, ch);
         if (next2 < p.ntiles) fetch_offsets(next2, fn2);
         {
             // reorder: all reads first (the first 16 bytes of every record, and where it
@@ -627,35 +628,55 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
                 head[k] = ov_lds_read16(sin, len[k] ? lo[k] : 0u);
                 dst[k] = wslot[w * OS_MAXP + (len[k] ? d[k] : 0u)] + pw[k];
             }
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                if (len[k] == 0) continue;
-                uint8_t *o = sout + dst[k];
-                if (len[k] >= 16) { // the rest of a longer record follows below
-                    *reinterpret_cast<OvU128 *>(o) = OvU128{head[k].x, head[k].y, head[k].z, head[k].w};
-                    continue;
+            // n <= 16 bytes out of four registers to any address of the image
+            auto put = [&](uint8_t *o, const uint4 &hd, uint32_t n) {
+                if (n >= 16) {
+                    *reinterpret_cast<OvU128 *>(o) = OvU128{hd.x, hd.y, hd.z, hd.w};
+                    return;
                 }
-                uint32_t a0 = head[k].x, a1 = head[k].y, a2 = head[k].z, a3 = head[k].w;
-                if (len[k] & 8u) {
+                uint32_t a0 = hd.x, a1 = hd.y, a2 = hd.z, a3 = hd.w;
+                if (n & 8u) {
                     reinterpret_cast<OvU64 *>(o)->v = (unsigned long long) a0 | ((unsigned long long) a1 << 32);
                     a0 = a2;
                     a1 = a3;
                     o += 8;
                 }
-                if (len[k] & 4u) {
+                if (n & 4u) {
                     reinterpret_cast<OvU32 *>(o)->v = a0;
                     a0 = a1;
                     o += 4;
                 }
-                if (len[k] & 2u) {
+                if (n & 2u) {
                     reinterpret_cast<OvU16 *>(o)->v = (uint16_t) a0;
                     a0 >>= 16;
                     o += 2;
                 }
-                if (len[k] & 1u) *o = (uint8_t) a0;
+                if (n & 1u) *o = (uint8_t) a0;
+            };
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (len[k]) put(sout + dst[k], head[k], len[k]);
+            // the rest of longer records: tails of a few bytes as unaligned pieces LDS -> LDS;
+            // when a lane has more, bytes 16..31 through registers as above, all reads first
+            bool more = false, much = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                more |= len[k] > 16;
+                much |= len[k] > 22;
             }
-            for (int k = 0; k < K; k++) // not unrolled: rare for short records
-                if (len[k] > 16) ov_copy_lds(sout + dst[k] + 16, sin + lo[k] + 16, len[k] - 16);
+            if (__any(much)) {
+#pragma unroll
+                for (int k = 0; k < K; k++) head[k] = ov_lds_read16(sin, len[k] > 16 ? lo[k] + 16 : 0u);
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (len[k] > 16) put(sout + dst[k] + 16, head[k], len[k] - 16);
+                for (int k = 0; k < K; k++) // not unrolled: rare
+                    if (len[k] > 32) ov_copy_lds(sout + dst[k] + 32, sin + lo[k] + 32, len[k] - 32);
+            }
+            else if (__any(more)) {
+                for (int k = 0; k < K; k++) // not unrolled
+                    if (len[k] > 16) ov_copy_lds(sout + dst[k] + 16, sin + lo[k] + 16, len[k] - 16);
+            }
         }
         OV_PHASE(5)
         __syncthreads(); // C: the staging buffer is free
