@@ -541,12 +541,15 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
             typedef void (*OvKernel)(OvParams);
 #define OVK(K, V) {k_onesweepv<kOvThreads, K, V, 4, 8, 0>, k_onesweepv<kOvThreads, K, V, 4, 8, 1>, \
                    k_onesweepv<kOvThreads, K, V, 4, 8, 2>}
-            static const OvKernel kernels[5][3] = {OVK(1, 0), OVK(2, 0), OVK(4, 0), OVK(4, OSV_STATS),
-                                                   OVK(4, OSV_STATS | OSV_FAKE_CHAIN)};
+            static const OvKernel kernels[7][3] = {OVK(1, 0), OVK(2, 0), OVK(4, 0), OVK(4, OSV_STATS),
+                                                   OVK(4, OSV_STATS | OSV_FAKE_CHAIN), OVK(4, OSV_NT_STORE),
+                                                   OVK(4, OSV_STATS | OSV_NT_STORE)};
 #undef OVK
             // MGS_OSV_STATS: diagnostic build (K = 4 only), per-phase cycle counts in Ctrl::head.stats
-            const char *sv = getenv("MGS_OSV_STATS"); // "2": also no chained scan (timing only, wrong output)
-            const int ki = ov_k == 1 ? 0 : (ov_k == 2 ? 1 : (sv ? (atoi(sv) == 2 ? 4 : 3) : 2));
+            // "2": also no chained scan, "3": no global stores and no counts, "4": counts without
+            // global stores (timing only, wrong output)
+            const char *sv = getenv("MGS_OSV_STATS");
+            const int ki = ov_k == 1 ? 0 : (ov_k == 2 ? 1 : (sv ? (atoi(sv) >= 2 && atoi(sv) <= 4 ? atoi(sv) + 2 : 3) : 2));
             hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
             h->pending_ov_k = ov_k;
             if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
