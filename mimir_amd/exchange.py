@@ -63,6 +63,11 @@ def exchange_payload(send_image, send_offset, recv_count, buf_size, recv_image,
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+        # MPI_Alltoallv returns when both images may be touched again.  On RCCL wait()
+        # only orders the current stream behind the transfer; the packer writes the send
+        # image from a stream of its own, so the host has to see the transfer end.
+        if send_image.is_cuda:
+            torch.cuda.current_stream(send_image.device).synchronize()
     return roff
 
 
