@@ -339,6 +339,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
 
     // ------------------------------------------------------------------ scan wave
     if (w == WORKERS) {
+        // every later tile waits for this wave's prefix: it goes first at the issue arbiter
+        __builtin_amdgcn_s_setprio(3);
         OsWalkStats ws;
         const unsigned long long my_base = pbase[lane], my_cap = pcap[lane];
         while (tile < p.ntiles) {

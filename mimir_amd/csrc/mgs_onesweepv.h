@@ -237,6 +237,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
 
     // ------------------------------------------------------------------ scan wave
     if (w == WORKERS) {
+        // every later tile waits for this wave's prefix: it goes first at the issue arbiter
+        __builtin_amdgcn_s_setprio(3);
         OsWalkStats ws;
         const bool live = (uint32_t) lane < PC, is_dest = (uint32_t) lane < P;
         const unsigned long long my_base = is_dest ? p.ctrl->head.part_base[lane] : 0ull;
