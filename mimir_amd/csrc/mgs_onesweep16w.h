@@ -462,6 +462,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
             }
         }
         __syncthreads(); // A: counts(tile) complete; image(prev) and position(prev) ready
+        // the phases that issue memory operations go before the other waves' hashing: the
+        // stores of the previous image, the reorder that frees the registers, the next loads
+        __builtin_amdgcn_s_setprio(1);
 
         uint32_t tot = 0, below = 0; // lane = destination
 #pragma unroll
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
         }
         // the registers are free again: fetch the next tile
         if (next < p.ntiles) os_load_tile<ITEMS, VAR>(p, next, TILE, w, lane, r);
+        __builtin_amdgcn_s_setprio(0);
         prev = tile;
         tile = next;
         par ^= 1;

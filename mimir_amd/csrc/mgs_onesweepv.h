@@ -593,6 +593,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
         OV_PHASE(1)
         __syncthreads(); // A: counts(tile) complete; tables of the previous tile are ready
         OV_PHASE(2)
+        // the phases that issue memory operations go before the other waves' hashing
+        __builtin_amdgcn_s_setprio(1);
 
         uint32_t tot = 0, below = 0; // lane = destination
 #pragma unroll
@@ -688,6 +690,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
         }
         fn = fn2;
         OV_PHASE(6)
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads(); // D: the next tile is staged
         OV_PHASE(7)
         have_prev = true;
