@@ -108,10 +108,9 @@ __device__ __forceinline__ void os_load_tile(const OsParams &p, uint32_t tile, i
         const uint64_t i = idx0 + (uint32_t) k * 64;
         if (i < p.n) {
             if (VAR & OSV_NT_LOAD) {
-                const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p.rec + i);
-                const unsigned long long lo = __builtin_nontemporal_load(q);
-                const unsigned long long hi = __builtin_nontemporal_load(q + 1);
-                r[k] = make_uint4((uint32_t) lo, (uint32_t)(lo >> 32), (uint32_t) hi, (uint32_t)(hi >> 32));
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p.rec + i));
+                r[k] = make_uint4(v.x, v.y, v.z, v.w);
             }
             else {
                 r[k] = p.rec[i];

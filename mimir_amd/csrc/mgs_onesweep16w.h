@@ -398,8 +398,17 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) {
                 const uint32_t s = (uint32_t) k * WTHREADS + tid;
-                if (s < total)
-                    *reinterpret_cast<uint4 *>(addr[sdest[s]] + ((unsigned long long) s << 4)) = srec[s];
+                if (s < total) {
+                    if (VAR & OSV_NT_STORE) {
+                        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                        const uint4 v = srec[s];
+                        __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w},
+                                                    reinterpret_cast<v4u *>(addr[sdest[s]] + ((unsigned long long) s << 4)));
+                    }
+                    else {
+                        *reinterpret_cast<uint4 *>(addr[sdest[s]] + ((unsigned long long) s << 4)) = srec[s];
+                    }
+                }
             }
             return;
         }
