@@ -67,17 +67,20 @@ def cpu_baseline(records_dev, n_total, target_seconds=12.0):
                       f"CollectiveShuffler::write) on one host core, {dt:.1f} s"}
 
 
-def cpu_baseline_multicore(n_total, procs=16):
-    """The same loop on `procs` host cores at once (one process per core, each a
-    rank with its own slice and its own send image), run as a child process that
-    never touches the GPU.  None if it cannot be run."""
+def cpu_baseline_multicore(n_total):
+    """The same loop on every physical core this job may use (one process per
+    core, each a rank with its own slice and its own send image), run as a child
+    process that never touches the GPU.  None if it cannot be run."""
     import subprocess
-    procs = max(1, min(procs, os.cpu_count() or 1))
+    cpus = host_cpus()
+    procs = max(1, min(cpus["physical"], cpus["share"]))
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_pack_baseline.py"),
            "--procs", str(procs), "--records", str(int(min(n_total, 1_000_000_000)))]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, check=True)
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["host_cpus"] = cpus
+        return out
     except Exception as e:  # the single-core figure stands in
         print(f"# multi-core CPU baseline not run: {e}", file=sys.stderr)
         return None
@@ -98,6 +101,62 @@ def committed_traffic(kernel_substr, n):
     return t.get("hbm_bytes_per_launch")
 
 
+def launch_ranks(n_ranks):
+    """`--gpus N` with N > 1 and no launcher around us: start the N ranks ourselves,
+    one process per GPU under torch.distributed.run, before this process has made
+    any GPU call (it never does), and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def host_cpus():
+    """What the host offers and what this job may use: logical CPUs, physical
+    cores (distinct (package, core) pairs of /proc/cpuinfo), and the job's share
+    (scheduler affinity, cgroup CPU quota, OMP_NUM_THREADS when a harness sets it)."""
+    logical = os.cpu_count() or 1
+    cores = set()
+    try:
+        pkg = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    pkg = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if core is not None:
+                        cores.add((pkg, core))
+                    pkg = core = None
+    except OSError:
+        pass
+    physical = len(cores) or logical
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            share = min(share, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        share = min(share, max(1, int(os.environ["OMP_NUM_THREADS"])))
+    except (KeyError, ValueError):
+        pass
+    return {"logical": logical, "physical": physical, "share": share}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +172,8 @@ def main():
     args = ap.parse_args()
     if args.workload != "u64" and args.records == 1e9:
         args.records = 5e7
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist

@@ -154,10 +154,22 @@ const char *mgs_last_error(const mgs_handle *h);
  *               (src/collectiveshuffler.h:143-144)
  *   d_local_out records whose destination is desc.rank, appended in emit
  *               order (the out->write bypass, :135-141); capacity local_cap
- *               bytes.  May be NULL when desc.rank == -1.
+ *               bytes.  May be NULL when desc.rank == -1.  Size it for the
+ *               local records of the whole examined range [start, min(n_end,
+ *               start + max_records)), not only of the part before the round
+ *               cut: the kernels place a tile's records before they know
+ *               where the round ends, and a local record that has no room
+ *               is MGS_ERR_LOCAL_OVERFLOW even when it lies after the cut.
  *   d_dest_out  optional, one byte per record of [start, n_end): its
  *               destination rank (hashlittle(key) % nranks)
- *   stream      hipStream_t, or NULL for the handle's own stream
+ *   stream      hipStream_t the kernels are enqueued on; the inputs must be
+ *               complete in that stream's order.  NULL: a stream the handle
+ *               owns, created as a blocking stream -- its work starts after
+ *               everything enqueued on the legacy default stream before the
+ *               call (a hipMemcpy of the records, a kernel launched on stream
+ *               0) and later default-stream work waits for it; work on other
+ *               non-blocking streams is NOT waited for.  The same holds for
+ *               every entry point below that takes a stream.
  *
  * At most desc.max_records records are examined; the call stops early at the
  * first record that does not fit its partition.  Blocks until the result is
@@ -170,7 +182,10 @@ int mgs_pack_device(mgs_handle *h, const void *d_records,
                     int algo, void *stream, mgs_round *out);
 
 /* Same kernels, enqueue only: returns as soon as the work is on `stream`.
- * mgs_pack_result() then waits for that work and fetches the result. */
+ * mgs_pack_result() then waits for that work and fetches the result.  One
+ * pack call may be in flight per handle; until its result has been fetched
+ * the handle's other device calls (unpack, tokenize, group, combine) return
+ * MGS_ERR_STATE, and another mgs_pack_device[_async] first waits for it. */
 int mgs_pack_device_async(mgs_handle *h, const void *d_records,
                           const uint32_t *d_rec_off, uint64_t n_end,
                           uint64_t start, const int64_t *init_offset,

@@ -279,7 +279,11 @@ int mgs_create(const mgs_desc *desc, mgs_handle **out)
     hipError_t e = hipGetDeviceProperties(&prop, desc->device);
     if (e != hipSuccess) return fail(e, "hipGetDeviceProperties");
     h->num_cus = prop.multiProcessorCount;
-    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess)
+    // A blocking stream: work enqueued on it starts after everything the caller has put
+    // on the legacy default stream before (hipMemcpy, kernels launched on stream 0), and
+    // later default-stream work waits for it -- the ordering a caller that passes
+    // stream == NULL expects.
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault)) != hipSuccess)
         return fail(e, "hipStreamCreate");
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -728,8 +732,9 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
                         + up(((size_t) p.nchunks + 1) * sizeof(uint64_t)) + up((size_t) p.nchunks * S * sizeof(uint32_t))
                         + up((size_t) p.nchunks * sizeof(uint32_t))
                         + up(tables * sizeof(uint16_t)) + up(tables);
-    if (h->pending) { // one call in flight per handle: the control block and the scratch are shared
-        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    if (h->pending) { // the control block and the scratch are shared with the pack call in flight
+        h->err = "mgs_unpack_device: a pack call is in flight on this handle (call mgs_pack_result first)";
+        return MGS_ERR_STATE;
     }
     { const int rc = ensure_unp_scratch(h, need); if (rc) return rc; }
     uint8_t *q = h->d_unp;
@@ -839,8 +844,9 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t need = up(2 * sizeof(uint64_t)) + up((size_t) p.nchunks * 3 * 64 * sizeof(uint32_t))
                         + up((size_t) p.nchunks * 3 * sizeof(uint32_t)) + up((size_t) p.nchunks * 3 * sizeof(uint64_t));
-    if (h->pending) { // one call in flight per handle: the control block and the scratch are shared
-        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    if (h->pending) { // the control block and the scratch are shared with the pack call in flight
+        h->err = "mgs_tokenize_device: a pack call is in flight on this handle (call mgs_pack_result first)";
+        return MGS_ERR_STATE;
     }
     { const int rc = ensure_unp_scratch(h, need); if (rc) return rc; }
     uint8_t *q = h->d_unp;
@@ -955,8 +961,9 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
                         + 3 * up((size_t) n_records * sizeof(uint32_t)) + up(((size_t) p.ntiles + 1) * sizeof(uint32_t))
                         + up((size_t) p.ntiles * (GRP_TILE / 64) * sizeof(uint64_t))
                         + up(sort_bytes);
-    if (h->pending) { // one call in flight per handle: the control block is shared
-        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    if (h->pending) { // the control block and the scratch are shared with the pack call in flight
+        h->err = "mgs_group_device: a pack call is in flight on this handle (call mgs_pack_result first)";
+        return MGS_ERR_STATE;
     }
     if (need > h->grp_bytes) {
         if (h->d_grp) {
@@ -1107,8 +1114,9 @@ int mgs_combine_device(mgs_handle *h, const void *d_records, const uint32_t *d_r
     const size_t need = up(sizeof(unsigned long long)) + 3 * up(slots * sizeof(uint32_t)) + 2 * up(n * sizeof(uint32_t))
                         + up(n) + up((size_t) q.ntiles * (GRP_TILE / 64) * sizeof(uint64_t)) + up(cols * sizeof(uint32_t))
                         + up(cols * sizeof(unsigned long long)) + up(n * sizeof(unsigned long long));
-    if (h->pending) { // one call in flight per handle: the control block is shared
-        MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
+    if (h->pending) { // the control block and the scratch are shared with the pack call in flight
+        h->err = "mgs_combine_device: a pack call is in flight on this handle (call mgs_pack_result first)";
+        return MGS_ERR_STATE;
     }
     if (need > h->grp_bytes) {
         if (h->d_grp) {

@@ -110,11 +110,9 @@ class DevicePacker:
         else:
             init, init_p = None, None
         if stream is None:
+            # torch's default stream is the legacy null stream: the library then uses a
+            # blocking stream of its own, ordered after what torch has enqueued there
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            if not stream:
-                # the library maps the null stream to its own non-blocking stream, which
-                # is not ordered after torch's default stream: finish what produced the inputs
-                torch.cuda.current_stream(self.device).synchronize()
         local_cap = local_out.numel() if local_out is not None else 0
         return (self.h, _ptr(records), _ptr(rec_off), n_end, start, init_p,
                 _ptr(send_image), _ptr(local_out), local_cap, _ptr(dest_out),
@@ -135,8 +133,6 @@ class DevicePacker:
         """Blocking CombineCollectiveShuffler::write over records [start, n_end): one
         round, partitions written from their beginning."""
         s = torch.cuda.current_stream(self.device).cuda_stream
-        if not s:  # see _args
-            torch.cuda.current_stream(self.device).synchronize()
         r = capi.Round()
         self._check(self.lib.mgs_combine_device(
             self.h, _ptr(records), _ptr(rec_off), n_end, start, op, _ptr(send_image),
@@ -170,8 +166,6 @@ def unpack_stream(packer, stream, nbytes, page_bytes=64 << 20, first_page_fill=0
     ncuts = C.c_int()
     cuts = (capi.PageCut * max_cuts)()
     s = torch.cuda.current_stream(packer.device).cuda_stream
-    if not s:  # see DevicePacker._args
-        torch.cuda.current_stream(packer.device).synchronize()
     packer._check(packer.lib.mgs_unpack_device(
         packer.h, _ptr(stream), nbytes, _ptr(rec_off), rec_off.numel(), page_bytes, first_page_fill,
         C.byref(n), cuts, max_cuts, C.byref(ncuts), C.c_void_p(s)))
@@ -193,8 +187,6 @@ def group_records(packer, records, n, rec_off=None, page_bytes=64 << 20, max_cut
     G, nc = C.c_uint64(), C.c_int()
     cuts = (C.c_uint64 * max(max_cuts, 1))()
     s = torch.cuda.current_stream(packer.device).cuda_stream
-    if not s:  # see DevicePacker._args
-        torch.cuda.current_stream(packer.device).synchronize()
     packer._check(packer.lib.mgs_group_device(
         packer.h, _ptr(records), _ptr(rec_off), n, _ptr(first), _ptr(start), cap, _ptr(values),
         page_bytes, C.byref(G), cuts, max_cuts, C.byref(nc), C.c_void_p(s)))
@@ -212,8 +204,6 @@ def tokenize_text(packer, text, nbytes, value=1, records=None, rec_off=None):
         rec_off = torch.empty(nbytes // 2 + 2, dtype=torch.int32, device=text.device)
     n, nb = C.c_uint64(), C.c_uint64()
     s = torch.cuda.current_stream(packer.device).cuda_stream
-    if not s:  # see DevicePacker._args
-        torch.cuda.current_stream(packer.device).synchronize()
     packer._check(packer.lib.mgs_tokenize_device(
         packer.h, _ptr(text), nbytes, value, _ptr(records), records.numel(), _ptr(rec_off),
         rec_off.numel(), C.byref(n), C.byref(nb), C.c_void_p(s)))

@@ -264,7 +264,30 @@ class Reference:
         L.ref_wordcount_map.restype = C.c_long
         L.ref_wordcount_map.argtypes = [C.c_void_p, C.c_long, C.c_uint64, C.c_void_p,
                                         C.c_long, C.c_void_p, C.c_long]
+        for name, extra in (("ref_parse_u64_u64", []), ("ref_parse_chars_u64", [C.c_int]),
+                            ("ref_parse_cstr_fixed", [C.c_int])):
+            fn = getattr(L, name)
+            fn.restype = C.c_long
+            fn.argtypes = [C.c_void_p, C.c_long] + extra + [C.c_void_p, C.c_long]
         self.L = L
+
+    def parse_records(self, shape, buf, arg=0):
+        """Record offsets of a receive stream, found by the reference's own
+        from_bytes / kv_from_bytes walk (save_data).  shape: "u64_u64",
+        "chars_u64" (arg = keycount) or "cstr_fixed" (arg = value bytes)."""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        work = np.zeros(len(buf) + 8, dtype=np.uint8)  # strlen may look one byte past a bad stream
+        work[:len(buf)] = buf
+        offs = np.zeros(len(buf) + 2, dtype=np.uint64)
+        if shape == "u64_u64":
+            n = self.L.ref_parse_u64_u64(work.ctypes.data, len(buf), offs.ctypes.data, len(buf) + 1)
+        elif shape == "chars_u64":
+            n = self.L.ref_parse_chars_u64(work.ctypes.data, len(buf), arg, offs.ctypes.data, len(buf) + 1)
+        else:
+            n = self.L.ref_parse_cstr_fixed(work.ctypes.data, len(buf), arg, offs.ctypes.data, len(buf) + 1)
+        if n < 0:
+            raise ValueError(f"reference parse failed ({n})")
+        return offs[:n + 1]
 
     def wordcount_map(self, text, value=1):
         """The reference's own line framing + serialisation over a text."""

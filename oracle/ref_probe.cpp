@@ -2,6 +2,8 @@
 // sources where they lie under /root/reference (never copied):
 //   * hashlittle()                     src/hash.cpp:152
 //   * bytestream<T>::to_bytes / size   src/serializer.h:40-223
+//   * bytestream<T>::from_bytes, Serializer::kv_from_bytes
+//                                      src/serializer.h:54-61, :100-129, :376-416
 //   * FileParser::to_line              src/fileparser.h:21-41
 // Only the header-only, allocation-free static members of serializer.h are
 // instantiated, so nothing from the reference's memory.cpp / mimir.cpp (which
@@ -119,6 +121,75 @@ long ref_wordcount_map(char *text, long nbytes, uint64_t value, char *out, long 
     }
     rec_off_out[nrec] = (uint64_t) opos;
     return nrec;
+}
+
+// ---- receive side: what save_data does with a source's bytes ------------------
+// (src/collectiveshuffler.h:563-585): kv_from_bytes record after record until the
+// source's count is used up.  Each function walks `nbytes` of wire-form records
+// with the REAL parse routines and writes the offset of every record, then the
+// end offset; returns the number of records, -1 if max_records is too small, -2 if
+// the walk runs past nbytes.  For value-typed K and V the real Serializer object
+// is used (its constructor allocates nothing for them, src/serializer.h:300-319);
+// for char* keys the object would need the reference's memory.cpp, so the two
+// static from_bytes calls are composed exactly as kv_from_bytes does (:398-410).
+long ref_parse_u64_u64(char *buf, long nbytes, uint64_t *rec_off, long max_records)
+{
+    Serializer<uint64_t, uint64_t> ser(1, 1);
+    long pos = 0, n = 0;
+    while (pos < nbytes) {
+        if (n >= max_records) return -1;
+        uint64_t *key = NULL, *val = NULL;
+        rec_off[n++] = (uint64_t) pos;
+        pos += ser.kv_from_bytes(&key, &val, buf + pos, (int) (nbytes - pos));
+    }
+    rec_off[n] = (uint64_t) pos;
+    return pos == nbytes ? n : -2;
+}
+
+long ref_parse_chars_u64(char *buf, long nbytes, int keycount, uint64_t *rec_off, long max_records)
+{
+    Serializer<char, uint64_t> ser(keycount, 1);
+    long pos = 0, n = 0;
+    while (pos < nbytes) {
+        if (n >= max_records) return -1;
+        char *key = NULL;
+        uint64_t *val = NULL;
+        rec_off[n++] = (uint64_t) pos;
+        pos += ser.kv_from_bytes(&key, &val, buf + pos, (int) (nbytes - pos));
+    }
+    rec_off[n] = (uint64_t) pos;
+    return pos == nbytes ? n : -2;
+}
+
+// <char*, V> with V a value type of vbytes bytes (8: wordcount; 16: join's SingleVal;
+// 0: void): key by bytestream<char*>::from_bytes, value by bytestream<V>::from_bytes.
+long ref_parse_cstr_fixed(char *buf, long nbytes, int vbytes, uint64_t *rec_off, long max_records)
+{
+    struct Blob16 { char b[16]; };
+    long pos = 0, n = 0;
+    while (pos < nbytes) {
+        if (n >= max_records) return -1;
+        rec_off[n++] = (uint64_t) pos;
+        char *key = NULL;
+        pos += bytestream<char *>::from_bytes(&key, 1, buf + pos);
+        if (vbytes == 8) {
+            uint64_t v;
+            pos += bytestream<uint64_t>::from_bytes(&v, 1, buf + pos);
+        }
+        else if (vbytes == 16) {
+            Blob16 v;
+            pos += bytestream<Blob16>::from_bytes(&v, 1, buf + pos);
+        }
+        else if (vbytes == 0) {
+            pos += bytestream<void>::from_bytes(NULL, 1, buf + pos);
+        }
+        else {
+            return -3;
+        }
+        if (pos > nbytes) return -2;
+    }
+    rec_off[n] = (uint64_t) pos;
+    return n;
 }
 
 } // extern "C"

@@ -103,6 +103,33 @@ def main():
                              "(src/filereader.h:152-171) + strtok_r split and <word,1> write as in "
                              "examples/wordcount.cpp:66-82, serialised by bytestream<T>::to_bytes",
                    "vectors": tok}, f, indent=0)
+    # 4. receive side: record boundaries found by the reference's own from_bytes /
+    #    kv_from_bytes walk over small receive streams (save_data).
+    from mimir_amd import datagen
+    parse = []
+    b, _, _ = datagen.u64_records(7, seed=3)
+    parse.append({"shape": "u64_u64", "arg": 0, "stream_hex": b.tobytes().hex()})
+    for level in (1, 8, 15):
+        b, _, _ = datagen.octree_records(9, level=level, seed=4)
+        parse.append({"shape": "chars_u64", "arg": level, "stream_hex": b.tobytes().hex()})
+    b, _, _ = datagen.word_records(12, n_unique=5, alpha=0.5, len_mean=5, seed=5)
+    parse.append({"shape": "cstr_fixed", "arg": 8, "stream_hex": b.tobytes().hex()})
+    # values full of zero bytes, empty words (a lone NUL), a 300-byte word
+    hand = b"".join(w + b"\0" + (v).to_bytes(8, "little")
+                    for w, v in [(b"a", 0), (b"", 0), (b"bc", 1 << 56), (b"x" * 300, 0), (b"", 256)])
+    parse.append({"shape": "cstr_fixed", "arg": 8, "stream_hex": hand.hex()})
+    b, _, _ = datagen.join_records(10, n_unique=4, len_mean=6, len_sd=1, seed=6)
+    parse.append({"shape": "cstr_fixed", "arg": 16, "stream_hex": b.tobytes().hex()})
+    parse.append({"shape": "cstr_fixed", "arg": 0, "stream_hex": b"one\0two\0\0three\0".hex()})
+    parse.append({"shape": "cstr_fixed", "arg": 8, "stream_hex": ""})
+    for v in parse:
+        stream = np.frombuffer(bytes.fromhex(v["stream_hex"]), dtype=np.uint8)
+        v["rec_off"] = [int(x) for x in ref.parse_records(v["shape"], stream, v["arg"])]
+    with open(os.path.join(HERE, "parse_vectors.json"), "w") as f:
+        json.dump({"source": "bytestream<T>::from_bytes / Serializer::kv_from_bytes walked as save_data does "
+                             "(src/serializer.h:54-61, :100-129, :376-416; src/collectiveshuffler.h:563-585)",
+                   "vectors": parse}, f, indent=0)
+    print(f"wrote {len(parse)} parse vectors")
     print(f"wrote {len(vectors)}+{len(seeded)} hash vectors, {len(wire)} wire vectors, {len(tok)} texts")
 
 

@@ -5,7 +5,11 @@
 // repeatedly and compared with a host replay.  Usage: div_check [first variant] [reps]
 // Seen so far: both variants agree with the host on every launch but, now and
 // then, the very first launch of a process on a fresh box, where one chunk's
-// counts are those of a stretch of zero bytes -- the upload, not the loop.
+// counts are those of a stretch of zero bytes.  To tell stale input from a wrong
+// kernel, every launch also leaves a checksum of the bytes each chunk's wave
+// actually read; on a mismatch the chunk is copied back from the device and
+// compared with the host bytes, and its checksum as seen by the kernel is printed
+// beside the host's.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -44,15 +48,17 @@ __device__ __forceinline__ uint32_t step(uint64_t nul, uint32_t state, uint32_t 
 
 template <int VARIANT>
 __global__ __launch_bounds__(64) void k_div(const uint8_t *s, uint64_t nbytes, uint32_t V, uint32_t chunk,
-                                            uint32_t *exit_state, uint32_t *count)
+                                            uint32_t *exit_state, uint32_t *count, uint32_t *csum)
 {
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x, S = V + 2;
     const uint64_t c0 = (uint64_t) c * chunk, c1 = min(nbytes, c0 + chunk);
-    uint32_t state = ((uint32_t) lane == V + 1) ? INKEY : (uint32_t) lane, n = 0;
+    uint32_t state = ((uint32_t) lane == V + 1) ? INKEY : (uint32_t) lane, n = 0, sum = 0;
     for (uint64_t off = c0; off < c1; off += 64) {
         const uint64_t i = off + lane;
-        const uint64_t nul = __ballot(i < nbytes && s[i] == 0);
+        const uint32_t byte = (i < c1) ? s[i] : 0u;
+        sum += byte * (uint32_t) (1 + (i & 0xffu));
+        const uint64_t nul = __ballot(i < nbytes && byte == 0 && i < c1);
         const uint32_t valid = (uint32_t) min((uint64_t) 64, c1 - off);
         if ((uint32_t) lane < S) state = step<VARIANT>(nul, state, V, valid, n);
     }
@@ -60,6 +66,8 @@ __global__ __launch_bounds__(64) void k_div(const uint8_t *s, uint64_t nbytes, u
         exit_state[c * S + lane] = state;
         count[c * S + lane] = n;
     }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor((int) sum, o);
+    if (lane == 0) csum[c] = sum;
 }
 
 static uint32_t h_step(uint64_t nul, uint32_t state, uint32_t V, uint32_t valid, uint32_t &n)
@@ -107,8 +115,16 @@ int main(int argc, char **argv)
             hex[c * S + x] = st;
             hcnt[c * S + x] = n;
         }
+    std::vector<uint32_t> hsum(nchunks), dsum(nchunks);
+    for (uint32_t c = 0; c < nchunks; c++) {
+        uint32_t sum = 0;
+        for (uint64_t i = (uint64_t) c * chunk; i < std::min<uint64_t>(nbytes, (uint64_t) (c + 1) * chunk); i++)
+            sum += (uint32_t) s[i] * (uint32_t) (1 + (i & 0xffu));
+        hsum[c] = sum;
+    }
     uint8_t *d_s;
-    uint32_t *d_ex, *d_cnt;
+    uint32_t *d_ex, *d_cnt, *d_sum;
+    hipMalloc(&d_sum, nchunks * 4);
     hipMalloc(&d_s, nbytes);
     hipMalloc(&d_ex, nchunks * S * 4);
     hipMalloc(&d_cnt, nchunks * S * 4);
@@ -119,10 +135,29 @@ int main(int argc, char **argv)
         const int variant = vi ^ first;
         int bad_runs = 0, bad_entries = 0;
         for (int rep = 0; rep < reps; rep++) {
-            if (variant == 0) hipLaunchKernelGGL(k_div<0>, dim3(nchunks), dim3(64), 0, 0, d_s, nbytes, V, chunk, d_ex, d_cnt);
-            else hipLaunchKernelGGL(k_div<1>, dim3(nchunks), dim3(64), 0, 0, d_s, nbytes, V, chunk, d_ex, d_cnt);
+            if (variant == 0) hipLaunchKernelGGL(k_div<0>, dim3(nchunks), dim3(64), 0, 0, d_s, nbytes, V, chunk, d_ex, d_cnt, d_sum);
+            else hipLaunchKernelGGL(k_div<1>, dim3(nchunks), dim3(64), 0, 0, d_s, nbytes, V, chunk, d_ex, d_cnt, d_sum);
             hipMemcpy(ex.data(), d_ex, ex.size() * 4, hipMemcpyDeviceToHost);
             hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(dsum.data(), d_sum, dsum.size() * 4, hipMemcpyDeviceToHost);
+            for (uint32_t c = 0; c < nchunks; c++) {
+                if (dsum[c] == hsum[c]) continue;
+                // what the wave read differs from the host bytes: is the device memory itself wrong now?
+                const uint64_t c0 = (uint64_t) c * chunk, len = std::min<uint64_t>(nbytes, c0 + chunk) - c0;
+                std::vector<uint8_t> back(len);
+                hipMemcpy(back.data(), d_s + c0, len, hipMemcpyDeviceToHost);
+                uint64_t diff = 0, first = len, zeros = 0;
+                for (uint64_t i = 0; i < len; i++)
+                    if (back[i] != s[c0 + i]) {
+                        diff++;
+                        zeros += back[i] == 0;
+                        if (first == len) first = i;
+                    }
+                printf("  rep %d variant %d chunk %u: the kernel read checksum %08x, host bytes give %08x; "
+                       "copied back afterwards %llu of %llu bytes differ (first at %llu, %llu of them zero)\n",
+                       rep, variant, c, dsum[c], hsum[c], (unsigned long long) diff, (unsigned long long) len,
+                       (unsigned long long) first, (unsigned long long) zeros);
+            }
             int bad = 0;
             for (size_t i = 0; i < ex.size(); i++) {
                 const bool b = ex[i] != hex[i] || cnt[i] != hcnt[i];
