@@ -194,6 +194,37 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records,
                           void *stream);
 int mgs_pack_result(mgs_handle *h, mgs_round *out);
 
+/* mgs_pack_device for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  Same arguments, same kernels and same result
+ * as mgs_pack_device with MGS_ALGO_AUTO, but the call allocates nothing: the
+ * device-side control block and the chained-scan arrays of the one-sweep
+ * kernels live in a static device array of the library (MGS_NOALLOC_SCAN_BYTES
+ * for the scan arrays; every GPU the library is used on holds its copy until the
+ * process ends), and the host side uses what mgs_create made for the handle.
+ *
+ * Limits (MGS_ERR_ARG with a message otherwise): layouts and rank counts the
+ * one-sweep kernels take (at most 64 ranks, 63 with a local rank for other than
+ * 16-byte records; fixed widths up to 79 bytes or variable width), and
+ * ceil(n / tile) * (8*columns + 16*ceil(columns/4)) <= MGS_NOALLOC_SCAN_BYTES
+ * with columns = nranks (+1 with a local rank, except 16-byte records) and
+ * tile = 3584 records of 16 bytes, 1792 / 896 / 448 otherwise (the largest
+ * whose bytes fit 35 KB): e.g. 1.5e8 <u64,u64> records or 6e7 wordcount
+ * records per call at 8 ranks.  Variable-width records too long for the
+ * kernel's LDS staging give MGS_ERR_RECORD_SIZE (mgs_pack_device falls back to
+ * its generic kernels there).
+ *
+ * All calls on one GPU share that GPU's array, whatever the handle: the array
+ * keeps the previous call's contents (each call clears what it needs zeroed),
+ * and two calls that overlap in time on one GPU race -- serialise them. */
+#define MGS_NOALLOC_SCAN_BYTES (4u << 20)
+int mgs_pack_device_noalloc(mgs_handle *h, const void *d_records,
+                            const uint32_t *d_rec_off, uint64_t n_end,
+                            uint64_t start, const int64_t *init_offset,
+                            void *d_send_image, void *d_local_out,
+                            int64_t local_cap, uint8_t *d_dest_out,
+                            void *stream, mgs_round *out);
+
 /* Name of the kernel path the last pack call on this handle ran
  * ("generic" / "onesweep16"). */
 const char *mgs_last_algo(const mgs_handle *h);

@@ -80,6 +80,9 @@ SYMBOLS = {
                                         _VP, _VP, _VP, C.c_int64, _VP, C.c_int,
                                         _VP]),
     "mgs_pack_result": (C.c_int, [_VP, C.POINTER(Round)]),
+    "mgs_pack_device_noalloc": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP,
+                                          _VP, _VP, C.c_int64, _VP, _VP,
+                                          C.POINTER(Round)]),
     "mgs_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "mgs_set_tuning": (C.c_int, [_VP, C.c_int]),
     "mgs_get_tuning": (C.c_int, [_VP]),

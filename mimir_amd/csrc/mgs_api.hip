@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -57,6 +58,37 @@ int fixed_record_bytes(const mgs_layout &l)
 
 } // namespace
 
+// ---- the no-allocation entry point's device memory ------------------------------
+// mgs_pack_device_noalloc runs the one-sweep kernels with their control block and
+// chained-scan arrays in this file-scope array instead of hipMalloc'ed buffers.
+// The name `scratch` is a host-side stand-in, not a device address: the address of
+// each GPU's copy is fetched once per device with hipGetSymbolAddress (mgs_create,
+// with that device current) and only that pointer is ever handed to kernels,
+// memsets and copies.
+constexpr size_t kNoallocCtrlBytes = (sizeof(Ctrl) + 255) / 256 * 256;
+constexpr size_t kNoallocScratchBytes = kNoallocCtrlBytes + MGS_NOALLOC_SCAN_BYTES;
+static __device__ __align__(256) unsigned char scratch[kNoallocScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static unsigned char *g_scratch_ptr[kMaxDevices]; // per device, nullptr until mgs_create ran there
+
+// Call with `device` current.
+static hipError_t noalloc_scratch_for(int device, unsigned char **out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 // Instantiations of the one-sweep kernel.  kDefaultOsVariant is what production
 // calls run; the rest are there to be timed against it (mgs_set_tuning,
 // tools/tune_onesweep.py): each prices one design decision on the hardware.
@@ -101,6 +133,7 @@ struct mgs_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the dominant kernel
     bool ev_valid = false;
     Ctrl *d_ctrl = nullptr;
+    unsigned char *d_noalloc = nullptr; // this device's copy of `scratch`
     CtrlHead *h_head = nullptr; // pinned, host -> device
     Ctrl *h_ctrl = nullptr;     // pinned, device -> host
     // generic path scratch
@@ -117,6 +150,7 @@ struct mgs_handle {
     size_t grp_bytes = 0;
     uint64_t *h_unp = nullptr;  // pinned: result + cuts
     bool pending_osv = false; // the byte-granular one-sweep path was enqueued (may have fallen back)
+    bool pending_noalloc = false; // ... through mgs_pack_device_noalloc: no generic kernels behind it
     int ov_k = 4;             // records per worker lane for variable-width input, adapted call by call
     int pending_ov_k = 4;
     // call in flight
@@ -288,6 +322,8 @@ int mgs_create(const mgs_desc *desc, mgs_handle **out)
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipMalloc(&h->d_ctrl, sizeof(Ctrl))) != hipSuccess) return fail(e, "hipMalloc(ctrl)");
+    if ((e = noalloc_scratch_for(desc->device, &h->d_noalloc)) != hipSuccess)
+        return fail(e, "hipGetSymbolAddress(scratch)");
     if ((e = hipHostMalloc(&h->h_head, sizeof(CtrlHead), hipHostMallocDefault)) != hipSuccess)
         return fail(e, "hipHostMalloc(head)");
     if ((e = hipHostMalloc(&h->h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
@@ -353,10 +389,13 @@ static int ov_pick_k(double bytes_per_record)
     return 0;
 }
 
-int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
-                          uint64_t n_end, uint64_t start, const int64_t *init_offset,
-                          void *d_send_image, void *d_local_out, int64_t local_cap,
-                          uint8_t *d_dest_out, int algo, void *stream_v)
+// Enqueue one pack call.  noalloc: the control block and the chained-scan arrays live
+// in the device's static scratch array, nothing is allocated, only the one-sweep
+// kernels are available.
+static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
+                        uint64_t n_end, uint64_t start, const int64_t *init_offset,
+                        void *d_send_image, void *d_local_out, int64_t local_cap,
+                        uint8_t *d_dest_out, int algo, void *stream_v, bool noalloc)
 {
     if (!h) return MGS_ERR_ARG;
     const mgs_desc &D = h->desc;
@@ -395,6 +434,30 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
     }
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
     const uint64_t n = std::min<uint64_t>(n_end - start, D.max_records);
+    Ctrl *d_ctrl = noalloc ? reinterpret_cast<Ctrl *>(h->d_noalloc) : h->d_ctrl;
+    unsigned long long *d_status = nullptr, *d_agg16 = nullptr;
+    // chained-scan arrays for `tiles` tiles of `columns` columns: the handle's buffers
+    // (grown on demand), or a carve-up of the static scratch (refused when too small)
+    auto scan_arrays = [&](int min_tile, int tile, int columns) -> int {
+        if (!noalloc) {
+            const int rc = ensure_onesweep_scratch(h, min_tile, columns);
+            d_status = h->d_status;
+            d_agg16 = h->d_agg16;
+            return rc;
+        }
+        const uint64_t tiles = (n + (uint64_t) tile - 1) / (uint64_t) tile;
+        const size_t sb = (tiles * (uint64_t) columns * sizeof(unsigned long long) + 255) / 256 * 256;
+        const size_t ab = tiles * (uint64_t) ((columns + 3) / 4 * 2) * sizeof(unsigned long long);
+        if (sb + ab > (size_t) MGS_NOALLOC_SCAN_BYTES) {
+            h->err = fmt("mgs_pack_device_noalloc: %llu records in tiles of %d need %zu bytes of scan arrays, "
+                         "the static scratch holds %zu: pass fewer records per call",
+                         (unsigned long long) n, tile, sb + ab, (size_t) MGS_NOALLOC_SCAN_BYTES);
+            return MGS_ERR_ARG;
+        }
+        d_status = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes);
+        d_agg16 = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes + sb);
+        return MGS_OK;
+    };
 
     h->pending_start = start;
     for (int b = 0; b < MGS_MAX_RANKS; b++)
@@ -404,6 +467,7 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
     h->ev_valid = false;
     if (n == 0) {
         h->pending = true;
+        h->pending_noalloc = noalloc;
         return MGS_OK;
     }
 
@@ -422,6 +486,11 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
     const int ov_k = h->fixed_len ? ov_pick_k((double) h->fixed_len) : h->ov_k;
     if (algo == MGS_ALGO_AUTO)
         algo = os_ok ? MGS_ALGO_ONESWEEP16 : (ov_ok ? MGS_ALGO_ONESWEEPV : MGS_ALGO_GENERIC);
+    if (noalloc && algo == MGS_ALGO_GENERIC) {
+        h->err = "mgs_pack_device_noalloc: this layout / rank count needs the generic kernels, whose buffers "
+                 "are allocated per handle (at most 64 ranks, fixed widths up to 79 bytes or variable width)";
+        return MGS_ERR_ARG;
+    }
     if (algo == MGS_ALGO_ONESWEEPV && !ov_ok) {
         h->err = "mgs_pack_device: ONESWEEPV needs nranks (+1 with a local rank) <= 64 and, for fixed "
                  "widths, records of at most 79 bytes";
@@ -459,10 +528,10 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
             H->part_init[b] = h->pending_init[b];
         }
     }
-    MGS_HIP(h, hipMemcpyAsync(h->d_ctrl, H, sizeof(CtrlHead), hipMemcpyHostToDevice, stream));
+    MGS_HIP(h, hipMemcpyAsync(d_ctrl, H, sizeof(CtrlHead), hipMemcpyHostToDevice, stream));
 
     if (algo == MGS_ALGO_ONESWEEP16) {
-        int rc = ensure_onesweep_scratch(h, os16_min_tile(), P);
+        int rc = scan_arrays(os16_min_tile(), kOsVariants[h->os_variant].tile, P);
         if (rc) return rc;
         OsParams p;
         p.rec = reinterpret_cast<const uint4 *>(rec0) + start;
@@ -482,15 +551,15 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         const OsVariant &V = kOsVariants[h->os_variant];
         p.tile_records = (uint32_t) V.tile;
         p.ntiles = (uint32_t)((n + p.tile_records - 1) / p.tile_records);
-        p.status = h->d_status;
-        p.agg16 = h->d_agg16;
+        p.status = d_status;
+        p.agg16 = d_agg16;
         p.lpt_log = p.nbits_pad > 2 ? p.nbits_pad - 2 : 0;
         p.unit_shift = 4;
         p.dest_out = d_dest_out;
-        p.ctrl = h->d_ctrl;
-        MGS_HIP(h, hipMemsetAsync(h->d_status, 0, (size_t) p.ntiles * P * sizeof(unsigned long long), stream));
+        p.ctrl = d_ctrl;
+        MGS_HIP(h, hipMemsetAsync(d_status, 0, (size_t) p.ntiles * P * sizeof(unsigned long long), stream));
         if (V.agg16)
-            MGS_HIP(h, hipMemsetAsync(h->d_agg16, 0, ((size_t) p.ntiles << p.lpt_log) * sizeof(unsigned long long), stream));
+            MGS_HIP(h, hipMemsetAsync(d_agg16, 0, ((size_t) p.ntiles << p.lpt_log) * sizeof(unsigned long long), stream));
         const uint32_t grid = std::min<uint32_t>(p.ntiles, (uint32_t)(h->num_cus * V.blocks_per_cu));
         MGS_HIP(h, hipEventRecord(h->ev0, stream));
         hipLaunchKernelGGL(V.kernel[p.nbits], dim3(grid), dim3(V.threads), 0, stream, p);
@@ -501,12 +570,15 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
     }
     else {
         const bool osv = algo == MGS_ALGO_ONESWEEPV;
-        const bool may_fall_back = osv && h->fixed_len == 0;
+        // variable width without the generic kernels behind it: a tile that does not fit the
+        // staging buffer is reported as an error by mgs_pack_result
+        const bool may_fall_back = osv && h->fixed_len == 0 && !noalloc;
+        const bool check_spans = osv && h->fixed_len == 0;
         h->pending_osv = osv;
         if (osv) {
             const int columns = P + (D.rank >= 0 ? 1 : 0);
             const int kOvTile = ov_tile(ov_k);
-            int rc = ensure_onesweep_scratch(h, kOvTile, columns);
+            int rc = scan_arrays(kOvTile, kOvTile, columns);
             if (rc) return rc;
             OvParams q;
             memset(&q, 0, sizeof(q));
@@ -530,13 +602,13 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
             c.fm = h->fm;
             c.tile_records = (uint32_t) kOvTile;
             c.ntiles = (uint32_t) ((n + kOvTile - 1) / kOvTile);
-            c.status = h->d_status;
-            c.agg16 = h->d_agg16;
+            c.status = d_status;
+            c.agg16 = d_agg16;
             c.dest_out = d_dest_out;
-            c.ctrl = h->d_ctrl;
-            MGS_HIP(h, hipMemsetAsync(h->d_status, 0, (size_t) c.ntiles * columns * sizeof(unsigned long long), stream));
-            MGS_HIP(h, hipMemsetAsync(h->d_agg16, 0, ((size_t) c.ntiles << c.lpt_log) * sizeof(unsigned long long), stream));
-            if (may_fall_back)
+            c.ctrl = d_ctrl;
+            MGS_HIP(h, hipMemsetAsync(d_status, 0, (size_t) c.ntiles * columns * sizeof(unsigned long long), stream));
+            MGS_HIP(h, hipMemsetAsync(d_agg16, 0, ((size_t) c.ntiles << c.lpt_log) * sizeof(unsigned long long), stream));
+            if (check_spans)
                 hipLaunchKernelGGL(k_osv_check, dim3((c.ntiles + 255) / 256), dim3(256), 0, stream, q);
             const uint32_t grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2));
             MGS_HIP(h, hipEventRecord(h->ev0, stream));
@@ -578,7 +650,7 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         p.tile_hist = h->d_tile_hist;
         p.tile_base = h->d_tile_base;
         p.dest = d_dest_out ? d_dest_out : h->d_dest;
-        p.ctrl = h->d_ctrl;
+        p.ctrl = d_ctrl;
         hipLaunchKernelGGL(k_gen_hist, dim3(p.ntiles), dim3(GEN_THREADS), 0, stream, p);
         hipLaunchKernelGGL(k_gen_scan, dim3(1), dim3(1024), 0, stream, p);
         if (!osv) MGS_HIP(h, hipEventRecord(h->ev0, stream));
@@ -589,9 +661,30 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *
         }
     }
     MGS_HIP(h, hipGetLastError());
-    MGS_HIP(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+    MGS_HIP(h, hipMemcpyAsync(h->h_ctrl, d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
     h->pending = true;
+    h->pending_noalloc = noalloc;
     return MGS_OK;
+}
+
+int mgs_pack_device_async(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
+                          uint64_t n_end, uint64_t start, const int64_t *init_offset,
+                          void *d_send_image, void *d_local_out, int64_t local_cap,
+                          uint8_t *d_dest_out, int algo, void *stream_v)
+{
+    return pack_enqueue(h, d_records, d_rec_off, n_end, start, init_offset, d_send_image, d_local_out,
+                        local_cap, d_dest_out, algo, stream_v, false);
+}
+
+int mgs_pack_device_noalloc(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
+                            uint64_t n_end, uint64_t start, const int64_t *init_offset,
+                            void *d_send_image, void *d_local_out, int64_t local_cap,
+                            uint8_t *d_dest_out, void *stream, mgs_round *out)
+{
+    int rc = pack_enqueue(h, d_records, d_rec_off, n_end, start, init_offset, d_send_image, d_local_out,
+                          local_cap, d_dest_out, MGS_ALGO_AUTO, stream, true);
+    if (rc) return rc;
+    return mgs_pack_result(h, out);
 }
 
 int mgs_pack_result(mgs_handle *h, mgs_round *out)
@@ -612,7 +705,14 @@ int mgs_pack_result(mgs_handle *h, mgs_round *out)
     DeviceGuard g(h->desc.device);
     MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
     h->ev_valid = true;
-    if (h->pending_osv && h->h_ctrl->head.fallback != 0) h->last_algo = "generic"; // fell back on the device
+    if (h->pending_osv && h->h_ctrl->head.fallback != 0) {
+        if (h->pending_noalloc) {
+            h->err = "mgs_pack_device_noalloc: a tile of records does not fit the kernel's LDS staging buffer "
+                     "(records too long); use mgs_pack_device";
+            return MGS_ERR_RECORD_SIZE;
+        }
+        h->last_algo = "generic"; // fell back on the device
+    }
     const int derr = h->h_ctrl->head.error;
     if (derr != 0) {
         switch (derr) {

@@ -128,6 +128,16 @@ class DevicePacker:
         self._check(self.lib.mgs_pack_device(*args, C.byref(r)))
         return RoundResult(r, self.nranks)
 
+    def pack_noalloc(self, records, n_end, send_image, start=0, rec_off=None,
+                     init_offset=None, local_out=None, dest_out=None, stream=None):
+        """mgs_pack_device_noalloc: the same call on the library's static device
+        scratch, allocating nothing."""
+        args, _keep = self._args(records, rec_off, n_end, start, init_offset,
+                                 send_image, local_out, dest_out, capi.ALGO_AUTO, stream)
+        r = capi.Round()
+        self._check(self.lib.mgs_pack_device_noalloc(*args[:10], args[11], C.byref(r)))
+        return RoundResult(r, self.nranks)
+
     def combine(self, records, n_end, send_image, start=0, rec_off=None, local_out=None,
                 op=capi.COMBINE_SUM_U64):
         """Blocking CombineCollectiveShuffler::write over records [start, n_end): one
