@@ -86,7 +86,7 @@ def cpu_baseline_multicore(n_total):
         return None
 
 
-def committed_traffic(kernel_substr, n):
+def committed_traffic(kernel_substr, n, rounds=1):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     PMC passes (FETCH_SIZE doubled: gfx950 tallies 128-byte reads as 64; both
     counters are in KiB), if such a profile exists for this kernel and size."""
@@ -96,7 +96,7 @@ def committed_traffic(kernel_substr, n):
             t = json.load(f)
     except OSError:
         return None
-    if t.get("records") != n or kernel_substr not in t.get("kernel", ""):
+    if t.get("records") != n or kernel_substr not in t.get("kernel", "") or t.get("rounds", 1) != rounds:
         return None
     return t.get("hbm_bytes_per_launch")
 
@@ -157,6 +157,14 @@ def host_cpus():
     return {"logical": logical, "physical": physical, "share": share}
 
 
+def parse_size(text):
+    """Sizes as MIMIR_COMM_SIZE takes them (src/mimir.cpp:75-131): a number with an
+    optional b/k/m/g suffix."""
+    t = str(text).strip().lower().rstrip("b")
+    mult = {"k": 1 << 10, "m": 1 << 20, "g": 1 << 30}.get(t[-1:], 1)
+    return int(float(t[:-1] if t[-1:] in "kmg" else t) * mult)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,12 +177,18 @@ def main():
                     help="u64: the headline configuration; words / join / octree: the other record "
                          "shapes (host-generated, default 5e7 records per GPU)")
     ap.add_argument("--level", type=int, default=12, help="octree: key characters per record")
+    ap.add_argument("--comm-size", default=None,
+                    help="MIMIR_COMM_SIZE: the send buffer of the reference (64M by default there); the "
+                         "partitions get the reference's geometry and the batch is cut into rounds as "
+                         "CollectiveShuffler::write cuts it.  0: one round sized to hold the whole batch. "
+                         "Default: 64M.")
     args = ap.parse_args()
     if args.workload != "u64" and args.records == 1e9:
         args.records = 5e7
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     from mimir_amd import capi
@@ -198,19 +212,18 @@ def main():
     n = int(args.records)
     P = 8 if not distributed else world
     self_rank = -1 if not distributed else rank
+    comm_size = parse_size(args.comm_size if args.comm_size is not None else "64M")
     algo = {"auto": capi.ALGO_AUTO, "generic": capi.ALGO_GENERIC,
             "onesweep16": capi.ALGO_ONESWEEP16, "onesweepv": capi.ALGO_ONESWEEPV}[args.algo]
     rec_off = None
     if args.workload == "u64":
         lay = capi.Layout.make(capi.KEY_FIXED, 8, capi.VAL_FIXED, 8)
-        # one round holds the whole batch: capacity = expected share + 1/64 slack
-        buf_size = 16 * (n // P + n // 64 + 4096)
         records = synth_u64_records(n, seed=42 + rank, first=rank * n, device=dev)
         total_bytes, algo_bytes = 16 * n, n * ALGO_BYTES_PER_RECORD
+        hot_share = 1.0 / P
         what, data = "configs[1]: fixed-width <uint64,uint64> records", \
             "synthetic (seeded splitmix64 keys, value = record index)"
     else:
-        import numpy as np
         from mimir_amd import datagen
         if args.workload == "words":   # gen_words-like corpus: Zipf over a vocabulary, word\0 + u64 count
             blob, offs, lt = datagen.word_records(n, 1_000_000, 1.0, 6, 1.0, seed=44 + rank)
@@ -226,35 +239,53 @@ def main():
         records = torch.from_numpy(blob).to(f"cuda:{dev}")
         if offs is not None:
             rec_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).to(f"cuda:{dev}")
-        # skewed keys: leave room for four times the even share
-        buf_size = (min(total_bytes, 4 * total_bytes // P) + 65536) // 16 * 16
+        hot_share = min(1.0, 4.0 / P)  # skewed keys: room for four times the even share
         algo_bytes = 2 * total_bytes + (4 * (n + 1) if offs is not None else 0)
         data = "synthetic (seeded host generator, mimir_amd/datagen.py)"
-    pk = DevicePacker(lay, P, self_rank, buf_size, max_records=n, device=dev)
-    image = pk.new_send_image()
-    local = torch.empty(buf_size, dtype=torch.uint8, device=f"cuda:{dev}") if distributed else None
-    recv = torch.empty(P * buf_size, dtype=torch.uint8, device=f"cuda:{dev}") if distributed else None
-    if distributed:
-        from mimir_amd.exchange import exchange_round
 
-    kernel_ms, pack_s, sent_max = [], [], 0
+    if comm_size:
+        # the reference's geometry (src/collectiveshuffler.h:33-53); rounds are cut by the data
+        buf_size, _, tlb = capi.geometry(comm_size, P)
+        if tlb != 0:
+            raise SystemExit("--comm-size above 1 GiB needs MPI count units of more than one byte "
+                             "(type_log_bytes > 0), which this path does not take")
+        max_rounds = int(total_bytes * hot_share / buf_size * 1.15) + 8
+        rounds_note = f"MIMIR_COMM_SIZE={comm_size} -> {buf_size}-byte partitions, rounds cut by the data"
+    else:
+        # one round holds the whole batch: capacity = expected share + slack
+        buf_size = (int(total_bytes * hot_share) + total_bytes // 64 + 65536) // 16 * 16
+        max_rounds = 1
+        rounds_note = "one round holds the batch"
+    stride = P * buf_size
+    pk = DevicePacker(lay, P, self_rank, buf_size, max_records=n, device=dev)
+    images = torch.empty(max_rounds * stride, dtype=torch.uint8, device=f"cuda:{dev}")
+    local = recv = None
+    if distributed:
+        local = torch.empty(int(total_bytes * hot_share) + total_bytes // 64 + 65536, dtype=torch.uint8,
+                            device=f"cuda:{dev}")
+        recv = torch.empty(max_rounds * stride, dtype=torch.uint8, device=f"cuda:{dev}")
+        from mimir_amd.exchange import exchange_rounds
+
+    kernel_ms, pack_s, stats = [], [], {"sent_max": 0, "rounds": 0, "exchanges": 0}
 
     def step():
-        nonlocal sent_max
         t0 = time.perf_counter()
-        r = pk.pack(records, n, image, rec_off=rec_off, local_out=local, algo=algo)
+        r = pk.pack_rounds(records, n, images, stride, max_rounds, rec_off=rec_off, local_out=local, algo=algo)
         pack_s.append(time.perf_counter() - t0)
         if r.next != n:
-            raise RuntimeError(f"round cut at {r.next}: partition capacity too small")
+            raise RuntimeError(f"{r.n_rounds} rounds used up at record {r.next} of {n}: raise max_rounds")
         kernel_ms.append(pk.last_kernel_ms())
-        if distributed and backend == "gloo":
-            recv_host = torch.empty(recv.shape, dtype=torch.uint8)
-            _, _, got = exchange_round(image.cpu(), r.send_offset, buf_size, recv_host)
-            recv[:got].copy_(recv_host[:got])
-        elif distributed:
-            exchange_round(image, r.send_offset, buf_size, recv)
+        stats["rounds"] = r.n_rounds
         if distributed:
-            sent_max = max(sent_max, int(max(r.send_offset)))
+            so = r.round_send_offset
+            if backend == "gloo":   # rehearsal: through host memory
+                host_recv = torch.empty(recv.shape, dtype=torch.uint8)
+                rc, R = exchange_rounds(images.cpu(), stride, so, buf_size, host_recv, stride)
+                recv.copy_(host_recv)
+            else:
+                rc, R = exchange_rounds(images, stride, so, buf_size, recv, stride)
+            stats["exchanges"] = R
+            stats["sent_max"] = max(stats["sent_max"], int(so.sum(axis=0).max()))
         return r
 
     def barrier():
@@ -280,12 +311,17 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = n * world * args.steps / dt
-    k_ms = sum(kernel_ms) / len(kernel_ms)
+    in_kernel = pk.last_algo() == "onesweep16" or max_rounds == 1 or stats["rounds"] == 1
+    # one kernel covers the step (16-byte records cut their rounds inside the kernel); the
+    # other layouts run one kernel sequence per round: price the pack calls' wall time then
+    k_ms = sum(kernel_ms) / len(kernel_ms) if in_kernel else sum(pack_s) / len(pack_s) * 1e3
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     kname = pk.tuning_name() if pk.last_algo() == "onesweep16" else pk.last_algo()
     # variant names start with the kernel family's letter (t = the plain kernel)
     kernel = {"onesweep16": "k_onesweep16" + ("<" if kname.startswith("t") else kname[:1]),
               "onesweepv": "k_onesweepv", "generic": "k_gen_scatter"}[pk.last_algo()]
+    if not in_kernel:
+        kernel += f" x {stats['rounds']} rounds (one kernel sequence per round; wall time of the pack calls)"
     out = {
         "metric": "device-resident KV records/s hash-partitioned & packed",
         "value": value,
@@ -307,11 +343,11 @@ def main():
                             if distributed else "")),
             "records_per_gpu": n, "record_bytes": total_bytes / n, "partitions": P,
             "local_bypass": distributed, "kernel_variant": kname,
-            "rounds": "one round holds the batch",
+            "partition_bytes": buf_size, "rounds": stats["rounds"], "rounds_note": rounds_note,
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": committed_traffic(kernel, n) if not distributed else None,
+                     "traffic": committed_traffic(kernel, n, stats["rounds"]) if not distributed else None,
                      "kernel": kernel, "kernel_ms": k_ms,
                      "algorithmic_bytes_per_launch": algo_bytes},
     }
@@ -319,15 +355,18 @@ def main():
         pack_only = n * world / (sum(pack_s) / len(pack_s))
         out["pack_only_records_per_s"] = pack_only
         xfer_s = dt / args.steps - sum(pack_s) / len(pack_s)
-        out["exchange"] = {"hottest_pair_bytes": sent_max, "exchange_ms": xfer_s * 1e3,
-                           "xgmi_floor_ms": sent_max / (XGMI_LINK_GBS * 1e9) * 1e3,
-                           "frac_of_xgmi_pair_roofline": (sent_max / (XGMI_LINK_GBS * 1e9)) / max(xfer_s, 1e-9)}
+        hot = stats["sent_max"]   # bytes of the busiest (this rank -> peer) pair over the whole step
+        out["exchange"] = {"exchanges": stats["exchanges"], "hottest_pair_bytes": hot,
+                           "exchange_ms": xfer_s * 1e3,
+                           "xgmi_floor_ms": hot / (XGMI_LINK_GBS * 1e9) * 1e3,
+                           "frac_of_xgmi_pair_roofline": (hot / (XGMI_LINK_GBS * 1e9)) / max(xfer_s, 1e-9)}
     if rank == 0 and not distributed and not args.no_cpu_baseline and args.workload == "u64":
-        del image
+        del images
         torch.cuda.empty_cache()
         single = cpu_baseline(records, n)
         out["cpu_baseline"] = cpu_baseline_multicore(n) or single
         out["cpu_baseline"]["single_core"] = {k: single[k] for k in ("value", "unit", "GBps", "sample")}
+        out["cpu_baseline"].setdefault("host_cpus", host_cpus())
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

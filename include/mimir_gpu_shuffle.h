@@ -194,6 +194,65 @@ int mgs_pack_device_async(mgs_handle *h, const void *d_records,
                           void *stream);
 int mgs_pack_result(mgs_handle *h, mgs_round *out);
 
+/* Many rounds per call.  CollectiveShuffler::write ends a round -- exchange_kv,
+ * every partition empty again -- whenever one record does not fit its partition
+ * (src/collectiveshuffler.h:148-160), so a large batch is a sequence of rounds
+ * whose boundaries depend on the data.  This call packs records [start, n_end)
+ * into up to max_rounds send images in one go: image k, at d_send_images +
+ * k * image_stride (image_stride >= nranks * buf_size), is byte for byte the
+ * send buffer of the k-th exchange, and the per-round arrays say what
+ * mgs_pack_device would have returned round after round:
+ *
+ *   round_next[k]            index of the first record after round k
+ *   round_send_offset[k*nranks + b]  bytes of partition b in image k
+ *   round_local_records[k] / round_local_bytes[k]
+ *                            local-bypass records emitted during round k: the
+ *                            local stream in d_local_out is continuous, round k's
+ *                            records follow those of round k-1
+ *   out->n_rounds            rounds begun (>= 1); rounds 0 .. n_rounds-2 ended
+ *                            with a record that did not fit.  out->next == n_end:
+ *                            the last round is still open (its send_offset may be
+ *                            handed to the next call as init_offset); out->next <
+ *                            n_end: max_rounds ran out, the last round ended at
+ *                            record out->next, which opens the round after it
+ *   init_offset              bytes already in the partitions of image 0
+ *
+ * For 16-byte records (MGS_ALGO_ONESWEEP16) the rounds are cut inside the
+ * one-sweep kernel: one launch for the whole batch, each record still read once
+ * and written once; the other layouts run one kernel sequence per round.  Any
+ * array pointer may be NULL.  The _async / _result pair exists for the
+ * in-kernel case only (MGS_ERR_ARG otherwise). */
+typedef struct mgs_rounds {
+    uint32_t n_rounds;
+    uint32_t reserved;
+    uint64_t next;           /* first record not consumed */
+    uint64_t packed_records; /* over all rounds */
+    uint64_t local_records;
+    int64_t local_bytes;
+} mgs_rounds;
+
+int mgs_pack_rounds_device(mgs_handle *h, const void *d_records,
+                           const uint32_t *d_rec_off, uint64_t n_end,
+                           uint64_t start, const int64_t *init_offset,
+                           void *d_send_images, int64_t image_stride,
+                           uint32_t max_rounds, void *d_local_out,
+                           int64_t local_cap, uint8_t *d_dest_out, int algo,
+                           void *stream, mgs_rounds *out, uint64_t *round_next,
+                           int64_t *round_send_offset,
+                           uint64_t *round_local_records,
+                           int64_t *round_local_bytes);
+int mgs_pack_rounds_device_async(mgs_handle *h, const void *d_records,
+                                 const uint32_t *d_rec_off, uint64_t n_end,
+                                 uint64_t start, const int64_t *init_offset,
+                                 void *d_send_images, int64_t image_stride,
+                                 uint32_t max_rounds, void *d_local_out,
+                                 int64_t local_cap, uint8_t *d_dest_out,
+                                 int algo, void *stream);
+int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next,
+                           int64_t *round_send_offset,
+                           uint64_t *round_local_records,
+                           int64_t *round_local_bytes);
+
 /* mgs_pack_device for callers that cannot allocate: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
  * counterpart in the reference.  Same arguments, same kernels and same result

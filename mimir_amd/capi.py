@@ -62,6 +62,12 @@ class Round(C.Structure):
                 ("send_offset", C.c_int64 * MGS_MAX_RANKS)]
 
 
+class Rounds(C.Structure):
+    _fields_ = [("n_rounds", C.c_uint32), ("reserved", C.c_uint32), ("next", C.c_uint64),
+                ("packed_records", C.c_uint64), ("local_records", C.c_uint64),
+                ("local_bytes", C.c_int64)]
+
+
 # every symbol include/mimir_gpu_shuffle.h declares: (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
@@ -80,6 +86,12 @@ SYMBOLS = {
                                         _VP, _VP, _VP, C.c_int64, _VP, C.c_int,
                                         _VP]),
     "mgs_pack_result": (C.c_int, [_VP, C.POINTER(Round)]),
+    "mgs_pack_rounds_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP, _VP, C.c_int64,
+                                         C.c_uint32, _VP, C.c_int64, _VP, C.c_int, _VP,
+                                         C.POINTER(Rounds), _VP, _VP, _VP, _VP]),
+    "mgs_pack_rounds_device_async": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP, _VP, C.c_int64,
+                                               C.c_uint32, _VP, C.c_int64, _VP, C.c_int, _VP]),
+    "mgs_pack_rounds_result": (C.c_int, [_VP, C.POINTER(Rounds), _VP, _VP, _VP, _VP]),
     "mgs_pack_device_noalloc": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP,
                                           _VP, _VP, C.c_int64, _VP, _VP,
                                           C.POINTER(Round)]),

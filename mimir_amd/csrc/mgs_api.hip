@@ -66,7 +66,8 @@ int fixed_record_bytes(const mgs_layout &l)
 // with that device current) and only that pointer is ever handed to kernels,
 // memsets and copies.
 constexpr size_t kNoallocCtrlBytes = (sizeof(Ctrl) + 255) / 256 * 256;
-constexpr size_t kNoallocScratchBytes = kNoallocCtrlBytes + MGS_NOALLOC_SCAN_BYTES;
+constexpr size_t kNoallocRoundBytes = 4096; // round table + result table of a one-round call
+constexpr size_t kNoallocScratchBytes = kNoallocCtrlBytes + kNoallocRoundBytes + MGS_NOALLOC_SCAN_BYTES;
 static __device__ __align__(256) unsigned char scratch[kNoallocScratchBytes];
 
 constexpr int kMaxDevices = 64;
@@ -144,6 +145,10 @@ struct mgs_handle {
     unsigned long long *d_status = nullptr;
     unsigned long long *d_agg16 = nullptr;
     size_t status_bytes = 0, agg16_bytes = 0;
+    // round-cutting kernels: round table (device), result table (device + pinned host)
+    unsigned long long *d_rt = nullptr, *d_rtab = nullptr, *h_rtab = nullptr;
+    size_t rt_words = 0, rtab_words = 0;
+    uint32_t pending_rounds = 0; // > 0: the call in flight leaves a result table for that many rounds
     uint8_t *d_unp = nullptr;   // receive-side scratch (chunk and piece tables, cuts, result)
     size_t unp_bytes = 0;
     uint8_t *d_grp = nullptr;   // reduce-side scratch (tables, sort buffers)
@@ -172,6 +177,30 @@ struct mgs_handle {
             return MGS_ERR_HIP;                                                 \
         }                                                                       \
     } while (0)
+
+// Round table ((R+1) entries of `columns` words + R+1 start words) and result table.
+static int ensure_round_tables(mgs_handle *h, uint32_t max_rounds, int columns, int P)
+{
+    const size_t rtw = ((size_t) max_rounds + 1) * ((size_t) columns + 1);
+    const size_t tabw = os_rtab_words(max_rounds, (uint32_t) P);
+    if (h->rt_words < rtw) {
+        if (h->d_rt) MGS_HIP(h, hipFree(h->d_rt));
+        h->d_rt = nullptr;
+        h->rt_words = 0;
+        MGS_HIP(h, hipMalloc(&h->d_rt, rtw * sizeof(unsigned long long)));
+        h->rt_words = rtw;
+    }
+    if (h->rtab_words < tabw) {
+        if (h->d_rtab) MGS_HIP(h, hipFree(h->d_rtab));
+        if (h->h_rtab) MGS_HIP(h, hipHostFree(h->h_rtab));
+        h->d_rtab = h->h_rtab = nullptr;
+        h->rtab_words = 0;
+        MGS_HIP(h, hipMalloc(&h->d_rtab, tabw * sizeof(unsigned long long)));
+        MGS_HIP(h, hipHostMalloc(&h->h_rtab, tabw * sizeof(unsigned long long), hipHostMallocDefault));
+        h->rtab_words = tabw;
+    }
+    return MGS_OK;
+}
 
 extern "C" {
 
@@ -248,6 +277,9 @@ void mgs_destroy(mgs_handle *h)
         if (h->d_dest) (void) hipFree(h->d_dest);
         if (h->d_status) (void) hipFree(h->d_status);
         if (h->d_agg16) (void) hipFree(h->d_agg16);
+        if (h->d_rt) (void) hipFree(h->d_rt);
+        if (h->d_rtab) (void) hipFree(h->d_rtab);
+        if (h->h_rtab) (void) hipHostFree(h->h_rtab);
         if (h->d_unp) (void) hipFree(h->d_unp);
         if (h->d_grp) (void) hipFree(h->d_grp);
         if (h->h_unp) (void) hipHostFree(h->h_unp);
@@ -324,6 +356,12 @@ int mgs_create(const mgs_desc *desc, mgs_handle **out)
     if ((e = hipMalloc(&h->d_ctrl, sizeof(Ctrl))) != hipSuccess) return fail(e, "hipMalloc(ctrl)");
     if ((e = noalloc_scratch_for(desc->device, &h->d_noalloc)) != hipSuccess)
         return fail(e, "hipGetSymbolAddress(scratch)");
+    // tables of a one-round call (the pinned one also serves mgs_pack_device_noalloc)
+    if (ensure_round_tables(h, 1, OS_MAXP, OS_MAXP) != MGS_OK) {
+        g_create_error = "mgs_create: " + h->err;
+        mgs_destroy(h);
+        return MGS_ERR_HIP;
+    }
     if ((e = hipHostMalloc(&h->h_head, sizeof(CtrlHead), hipHostMallocDefault)) != hipSuccess)
         return fail(e, "hipHostMalloc(head)");
     if ((e = hipHostMalloc(&h->h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
@@ -395,7 +433,8 @@ static int ov_pick_k(double bytes_per_record)
 static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
                         uint64_t n_end, uint64_t start, const int64_t *init_offset,
                         void *d_send_image, void *d_local_out, int64_t local_cap,
-                        uint8_t *d_dest_out, int algo, void *stream_v, bool noalloc)
+                        uint8_t *d_dest_out, int algo, void *stream_v, bool noalloc,
+                        uint32_t max_rounds = 1, int64_t image_stride = 0)
 {
     if (!h) return MGS_ERR_ARG;
     const mgs_desc &D = h->desc;
@@ -454,8 +493,8 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                          (unsigned long long) n, tile, sb + ab, (size_t) MGS_NOALLOC_SCAN_BYTES);
             return MGS_ERR_ARG;
         }
-        d_status = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes);
-        d_agg16 = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes + sb);
+        d_status = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes + kNoallocRoundBytes);
+        d_agg16 = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes + kNoallocRoundBytes + sb);
         return MGS_OK;
     };
 
@@ -464,6 +503,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         h->pending_init[b] = (b < P && init_offset && b != D.rank) ? init_offset[b] : 0;
     h->pending_stream = stream;
     h->pending_empty = (n == 0);
+    h->pending_rounds = 0;
     h->ev_valid = false;
     if (n == 0) {
         h->pending = true;
@@ -561,10 +601,44 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         if (V.agg16)
             MGS_HIP(h, hipMemsetAsync(d_agg16, 0, ((size_t) p.ntiles << p.lpt_log) * sizeof(unsigned long long), stream));
         const uint32_t grid = std::min<uint32_t>(p.ntiles, (uint32_t)(h->num_cus * V.blocks_per_cu));
+        unsigned long long *d_tab = nullptr;
+        if (V.agg16) {
+            // the round-cutting kernel: round table + result table
+            if (noalloc) {
+                unsigned long long *base = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes);
+                p.rt = base;
+                d_tab = base + 2 * ((size_t) P + 1);
+                static_assert((2 * (OS_MAXP + 1) + OS_RTAB_HEAD + 3 + OS_MAXP) * 8 <= kNoallocRoundBytes, "round region");
+            }
+            else {
+                rc = ensure_round_tables(h, max_rounds, P, P);
+                if (rc) return rc;
+                p.rt = h->d_rt;
+                d_tab = h->d_rtab;
+            }
+            p.rt_start = p.rt + ((size_t) max_rounds + 1) * P;
+            p.max_rounds = max_rounds;
+            p.image_stride = (uint64_t) image_stride;
+            MGS_HIP(h, hipMemsetAsync(p.rt, 0, ((size_t) max_rounds + 1) * ((size_t) P + 1) * sizeof(unsigned long long), stream));
+        }
+        else if (max_rounds != 1) {
+            h->err = "this tuning variant of the one-sweep kernel packs one round per call";
+            return MGS_ERR_ARG;
+        }
         MGS_HIP(h, hipEventRecord(h->ev0, stream));
         hipLaunchKernelGGL(V.kernel[p.nbits], dim3(grid), dim3(V.threads), 0, stream, p);
         MGS_HIP(h, hipEventRecord(h->ev1, stream));
-        hipLaunchKernelGGL(k_os_finalize, dim3(1), dim3(64), 0, stream, p);
+        if (V.agg16) {
+            const size_t items = (size_t) max_rounds * ((size_t) P + 1);
+            hipLaunchKernelGGL(k_os_rounds_final, dim3((unsigned) std::min<size_t>(256, (items + 255) / 256)), dim3(256), 0,
+                               stream, p, (uint32_t) P, (uint32_t) (D.rank >= 0 ? D.rank : 0), d_tab);
+            MGS_HIP(h, hipMemcpyAsync(h->h_rtab, d_tab, os_rtab_words(max_rounds, (uint32_t) P) * sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, stream));
+            h->pending_rounds = max_rounds;
+        }
+        else {
+            hipLaunchKernelGGL(k_os_finalize, dim3(1), dim3(64), 0, stream, p);
+        }
         h->last_algo = "onesweep16";
         h->pending_osv = false;
     }
@@ -726,7 +800,24 @@ int mgs_pack_result(mgs_handle *h, mgs_round *out)
         }
         return derr;
     }
-    *out = h->h_ctrl->result;
+    if (h->pending_rounds) {
+        // a round-cutting kernel: round 0 of its result table (a one-round call ends at the
+        // first record that does not fit, src/collectiveshuffler.h:148)
+        const unsigned long long *tab = h->h_rtab;
+        const size_t R = h->pending_rounds;
+        out->next = tab[1];
+        out->packed_records = tab[2];
+        out->local_records = tab[3];
+        out->local_bytes = (int64_t) tab[4];
+        for (int b = 0; b < P; b++) out->send_offset[b] = (int64_t) tab[OS_RTAB_HEAD + 3 * R + b];
+        if (R != 1) {
+            h->err = "mgs_pack_result: the call in flight packs several rounds (use mgs_pack_rounds_result)";
+            return MGS_ERR_STATE;
+        }
+    }
+    else {
+        *out = h->h_ctrl->result;
+    }
     for (int b = P; b < MGS_MAX_RANKS; b++) out->send_offset[b] = 0;
     if (h->fixed_len == 0) {
         // Variable width: pick the next call's tile from this call's record length
@@ -755,6 +846,149 @@ int mgs_pack_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_
                                    d_send_image, d_local_out, local_cap, d_dest_out, algo, stream);
     if (rc) return rc;
     return mgs_pack_result(h, out);
+}
+
+// ---- many rounds per call ------------------------------------------------------------
+static bool rounds_in_kernel(const mgs_handle *h, const void *d_records, void *d_send_images, int64_t image_stride,
+                             void *d_local_out, const int64_t *init_offset, int algo)
+{
+    // the 16-byte one-sweep kernel cuts rounds itself (same conditions as in pack_enqueue)
+    const mgs_desc &D = h->desc;
+    bool ok = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEP16) && kOsVariants[h->os_variant].agg16
+              && h->fixed_len == 16 && D.nranks <= OS_MAXP && D.layout.key_kind == MGS_KEY_FIXED
+              && D.layout.key_bytes <= 16 && (D.buf_size % 16) == 0 && ((uintptr_t) d_records % 16) == 0
+              && ((uintptr_t) d_send_images % 16) == 0 && (image_stride % 16) == 0
+              && (D.rank < 0 || ((uintptr_t) d_local_out % 16) == 0);
+    for (int b = 0; b < D.nranks && ok && init_offset; b++) ok = (init_offset[b] % 16) == 0;
+    return ok;
+}
+
+int mgs_pack_rounds_device_async(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
+                                 uint64_t start, const int64_t *init_offset, void *d_send_images,
+                                 int64_t image_stride, uint32_t max_rounds, void *d_local_out, int64_t local_cap,
+                                 uint8_t *d_dest_out, int algo, void *stream)
+{
+    if (!h) return MGS_ERR_ARG;
+    if (max_rounds < 1 || image_stride < (int64_t) h->desc.nranks * h->desc.buf_size) {
+        h->err = "mgs_pack_rounds_device: max_rounds >= 1 and image_stride >= nranks * buf_size required";
+        return MGS_ERR_ARG;
+    }
+    if (!rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo)) {
+        h->err = "mgs_pack_rounds_device_async: this layout packs one round per kernel sequence; use the "
+                 "blocking mgs_pack_rounds_device";
+        return MGS_ERR_ARG;
+    }
+    return pack_enqueue(h, d_records, d_rec_off, n_end, start, init_offset, d_send_images, d_local_out, local_cap,
+                        d_dest_out, MGS_ALGO_ONESWEEP16, stream, false, max_rounds, image_stride);
+}
+
+int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next, int64_t *round_send_offset,
+                           uint64_t *round_local_records, int64_t *round_local_bytes)
+{
+    if (!h || !out) return MGS_ERR_ARG;
+    if (!h->pending) {
+        h->err = "mgs_pack_rounds_result: no pack call in flight";
+        return MGS_ERR_STATE;
+    }
+    const uint32_t R = h->pending_rounds;
+    const int P = h->desc.nranks;
+    memset(out, 0, sizeof(*out));
+    if (h->pending_empty) {
+        h->pending = false;
+        out->n_rounds = 1;
+        out->next = h->pending_start;
+        if (round_next) round_next[0] = h->pending_start;
+        if (round_local_records) round_local_records[0] = 0;
+        if (round_local_bytes) round_local_bytes[0] = 0;
+        if (round_send_offset)
+            for (int b = 0; b < P; b++) round_send_offset[b] = h->pending_init[b];
+        return MGS_OK;
+    }
+    if (R == 0) {
+        h->err = "mgs_pack_rounds_result: the call in flight is a one-round call (use mgs_pack_result)";
+        return MGS_ERR_STATE;
+    }
+    h->pending_rounds = 1; // mgs_pack_result checks errors and reads round 0
+    mgs_round r0;
+    const int rc = mgs_pack_result(h, &r0);
+    if (rc) return rc;
+    const unsigned long long *tab = h->h_rtab;
+    out->n_rounds = (uint32_t) tab[0];
+    out->next = tab[1];
+    out->packed_records = tab[2];
+    out->local_records = tab[3];
+    out->local_bytes = (int64_t) tab[4];
+    for (uint32_t k = 0; k < out->n_rounds; k++) {
+        if (round_next) round_next[k] = tab[OS_RTAB_HEAD + k];
+        if (round_local_records) round_local_records[k] = tab[OS_RTAB_HEAD + (size_t) R + k];
+        if (round_local_bytes) round_local_bytes[k] = (int64_t) tab[OS_RTAB_HEAD + 2 * (size_t) R + k];
+        if (round_send_offset)
+            for (int b = 0; b < P; b++)
+                round_send_offset[(size_t) k * P + b] = (int64_t) tab[OS_RTAB_HEAD + 3 * (size_t) R + (size_t) k * P + b];
+    }
+    return MGS_OK;
+}
+
+int mgs_pack_rounds_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
+                           uint64_t start, const int64_t *init_offset, void *d_send_images, int64_t image_stride,
+                           uint32_t max_rounds, void *d_local_out, int64_t local_cap, uint8_t *d_dest_out, int algo,
+                           void *stream, mgs_rounds *out, uint64_t *round_next, int64_t *round_send_offset,
+                           uint64_t *round_local_records, int64_t *round_local_bytes)
+{
+    if (!h || !out) return MGS_ERR_ARG;
+    if (max_rounds < 1 || image_stride < (int64_t) h->desc.nranks * h->desc.buf_size) {
+        h->err = "mgs_pack_rounds_device: max_rounds >= 1 and image_stride >= nranks * buf_size required";
+        return MGS_ERR_ARG;
+    }
+    if (rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo)) {
+        const int rc = mgs_pack_rounds_device_async(h, d_records, d_rec_off, n_end, start, init_offset, d_send_images,
+                                                    image_stride, max_rounds, d_local_out, local_cap, d_dest_out, algo,
+                                                    stream);
+        if (rc) return rc;
+        return mgs_pack_rounds_result(h, out, round_next, round_send_offset, round_local_records, round_local_bytes);
+    }
+    // Kernels that pack one round per launch sequence: one call per round (more when a
+    // round outlasts the handle's max_records), the local stream and the destination
+    // bytes advancing with the records.
+    const int P = h->desc.nranks;
+    memset(out, 0, sizeof(*out));
+    out->next = start;
+    uint64_t cur = start, lrec_k = 0;
+    int64_t lused = 0, lbytes_k = 0;
+    int64_t so[MGS_MAX_RANKS];
+    for (int b = 0; b < MGS_MAX_RANKS; b++) so[b] = (init_offset && b < P) ? init_offset[b] : 0;
+    uint32_t k = 0;
+    for (;;) {
+        mgs_round r;
+        const int rc = mgs_pack_device(h, d_records, d_rec_off, n_end, cur, so,
+                                       static_cast<uint8_t *>(d_send_images) + (size_t) k * (size_t) image_stride,
+                                       d_local_out ? static_cast<uint8_t *>(d_local_out) + lused : nullptr,
+                                       local_cap - lused, d_dest_out ? d_dest_out + (cur - start) : nullptr, algo, stream,
+                                       &r);
+        if (rc) return rc;
+        const uint64_t consumed = r.next - cur;
+        cur = r.next;
+        lused += r.local_bytes;
+        lrec_k += r.local_records;
+        lbytes_k += r.local_bytes;
+        out->packed_records += r.packed_records;
+        out->local_records += r.local_records;
+        out->local_bytes += r.local_bytes;
+        out->next = cur;
+        for (int b = 0; b < P; b++) so[b] = r.send_offset[b];
+        if (cur < n_end && consumed == h->desc.max_records) continue; // same round, next stretch of records
+        if (round_next) round_next[k] = cur;
+        if (round_local_records) round_local_records[k] = lrec_k;
+        if (round_local_bytes) round_local_bytes[k] = lbytes_k;
+        if (round_send_offset)
+            for (int b = 0; b < P; b++) round_send_offset[(size_t) k * P + b] = so[b];
+        out->n_rounds = ++k;
+        if (cur >= n_end || k == max_rounds) break;
+        for (int b = 0; b < P; b++) so[b] = 0;
+        lrec_k = 0;
+        lbytes_k = 0;
+    }
+    return MGS_OK;
 }
 
 int mgs_get_desc(const mgs_handle *h, mgs_desc *out)

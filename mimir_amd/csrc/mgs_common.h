@@ -170,6 +170,8 @@ struct CtrlHead {
     uint32_t ticket;              // one-sweep path: next tile to hand out
     int32_t error;                // first mgs_status raised on the device
     uint32_t fallback;            // byte-granular one-sweep path: 1 = a tile does not fit LDS, run the generic path
+    uint32_t rounds_cut;          // round-cutting kernels: round cuts published so far (= index of the last round begun)
+    uint32_t pad0;
     uint64_t part_base[MGS_MAX_RANKS]; // device address of each partition's byte 0
     int64_t part_cap[MGS_MAX_RANKS];   // capacity in bytes
     int64_t part_init[MGS_MAX_RANKS];  // bytes already there

@@ -70,7 +70,20 @@ struct OsParams {
     uint32_t unit_shift;        // log2 of the bytes one counted unit stands for (4: 16-byte records, 0: bytes)
     uint8_t *dest_out;          // optional
     Ctrl *ctrl;
+    // Rounds (k_onesweep16q and later kernels): one launch fills up to max_rounds send
+    // images.  Round k's image is the caller's image k: partition b at part_base[b] +
+    // k * image_stride.  Entry k of the round table describes the START of round k:
+    // rt[k * P + b] = units of column b before the round's first record (flagged with
+    // OS_RT_VALID; entry 0 is all zero by definition and never read), rt_start[k] = that
+    // record's index in this call.  Entry max_rounds is the end marker: records from
+    // there on are not consumed.
+    unsigned long long *rt;
+    unsigned long long *rt_start;
+    uint32_t max_rounds;
+    uint64_t image_stride;
 };
+
+constexpr unsigned long long OS_RT_VALID = 1ull << 63;
 
 __device__ __forceinline__ unsigned long long os_load_status(const unsigned long long *p)
 {

@@ -288,6 +288,155 @@ __device__ __forceinline__ void os_hash_rows(const OsParams &p, const uint4 (&r)
     }
 }
 
+
+// ---- rounds ------------------------------------------------------------------------
+// A round (src/collectiveshuffler.h:148-160) ends before the first record that does
+// not fit its partition; every partition then starts again from empty.  In terms of
+// the chained scan's running totals C_b(r) (units of column b before record r, never
+// reset): with B_k the totals at the first record of round k, record r of round k
+// goes to position C_b(r) - B_k[b] of image k, and the round is cut at the first r
+// with C_b(r) + size(r) - B_k[b] > capacity, i.e. C_b(r+1) > B_k[b] + cap[b] =: lim.
+// Totals only grow, so a tile knows from its own exclusive prefix `acc` alone whether
+// a cut lies before it (acc[b] > lim[b] for some b) and, with its counts, whether one
+// lies inside it (acc + tot > lim).  The tile that holds a cut finds the exact record,
+// publishes the new round's B in the round table and later tiles pick it up there.
+
+// Wait for entry k of the round table (lane = column) and return its word.
+__device__ __forceinline__ unsigned long long os_rt_wait(const OsParams &p, uint32_t k, int lane, bool live)
+{
+    unsigned long long v = OS_RT_VALID;
+    uint32_t idle = 0;
+    for (;;) {
+        if (live) v = os_load_status(p.rt + (uint64_t) k * p.P + lane);
+        if (__ballot((v & OS_RT_VALID) == 0) == 0) break;
+        if (++idle > OS_SPIN_LIMIT) {
+            raise_error(p.ctrl, MGS_ERR_TIMEOUT);
+            break;
+        }
+        if ((idle & 255u) == 0
+            && __hip_atomic_load(&p.ctrl->head.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return v & ~OS_RT_VALID;
+}
+
+// LDS the scan wave uses while it looks for round cuts inside its tile.
+struct OsCutLds {
+    volatile unsigned long long pos[OS_MAXP]; // lane = column: units before the current row
+    volatile unsigned long long lim[OS_MAXP]; // lane = column: B + capacity of the current round (~0: never cut)
+    volatile uint32_t cnt[OS_MAXP];           // scratch: units of a column in a row before a cut
+};
+
+// The tile `tile` (16-byte records) starts in round k_cur and holds at least one cut.
+// Finds every cut of the tile in emit order, publishes the rounds they begin and
+// leaves k_cur / base / lim at the state after the tile.  One wave; lane = column for
+// acc / tot / base / lim / my_cap, lane = record inside the row walk.  `wc` holds the
+// tile's counts per (worker wave, destination): the first cut is looked for only from
+// the first wave segment that overflows.
+template <int NB, int SEG>
+__device__ __forceinline__ void os_find_cuts16(const OsParams &p, uint32_t tile, int nseg, int lane,
+                                            unsigned long long acc, uint32_t tot, const uint32_t *wc,
+                                            bool is_part, unsigned long long my_cap, uint32_t &k_cur,
+                                            unsigned long long &base, unsigned long long &lim,
+                                            unsigned long long &first_nb, OsCutLds *x)
+{
+    const uint32_t P = p.P;
+    const uint32_t k_in = k_cur;
+    uint32_t c = 0, wst = (uint32_t) nseg;
+    for (int ww = 0; ww < nseg; ww++) {
+        const uint32_t v = wc[ww * OS_MAXP + lane];
+        if (is_part && wst == (uint32_t) nseg && acc + c + v > lim) wst = (uint32_t) ww;
+        c += v;
+    }
+    uint32_t wstar = (uint32_t) nseg;
+    for (int ww = nseg - 1; ww >= 0; ww--)
+        if (__ballot(wst == (uint32_t) ww)) wstar = (uint32_t) ww;
+    uint32_t run = 0;
+    for (int ww = 0; ww < nseg; ww++)
+        if ((uint32_t) ww < wstar) run += wc[ww * OS_MAXP + lane];
+    x->pos[lane] = acc + run;
+    x->lim[lane] = is_part ? lim : ~0ull;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t t0 = (uint64_t) tile * p.tile_records;
+    bool stop = false;
+    // One wave segment (SEG rows of 64 records) at a time: all its records are requested
+    // at once, so that the walk waits for memory once per segment and not once per row
+    // (a round trip takes microseconds while the chip streams, and every later tile
+    // waits for the round this walk publishes).
+    for (int seg = (int) wstar; seg < nseg && !stop; seg++) {
+    static_assert(SEG <= 8, "the destinations of a segment's rows are packed into two registers");
+    uint4 rr[SEG];
+#pragma unroll
+    for (int j = 0; j < SEG; j++) {
+        const uint64_t i = t0 + (uint32_t) (seg * SEG + j) * 64 + lane;
+        rr[j] = (i < p.n) ? p.rec[i] : make_uint4(0, 0, 0, 0);
+    }
+    uint32_t dpack[2] = {0, 0}; // destination of this lane's record in row j: byte j
+#pragma unroll
+    for (int j = 0; j < SEG; j++)
+        dpack[j >> 2] |= fastmod(hash_rec16(rr[j].x, rr[j].y, rr[j].z, rr[j].w, p.klen), p.fm) << (8 * (j & 3));
+#pragma unroll 1
+    for (int j = 0; j < SEG; j++) {
+        if (stop) break;
+        const int row = seg * SEG + j;
+        const uint64_t i = t0 + (uint32_t) row * 64 + lane;
+        const bool valid = i < p.n;
+        const uint32_t d = ((j < 4 ? dpack[0] : dpack[1]) >> (8 * (j & 3))) & 0xffu;
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (uint32_t bit = 0; bit < (uint32_t) NB; bit++) {
+            const bool one = (d >> bit) & 1u;
+            const uint64_t bk = __ballot(one);
+            m &= one ? bk : ~bk;
+        }
+        const uint32_t rank = lanes_below(m);
+        uint64_t open = ~0ull; // lanes not yet given to a finished round
+        for (;;) {
+            const bool over = valid && ((open >> lane) & 1ull) && x->pos[d] + rank >= x->lim[d];
+            const uint64_t om = __ballot(over);
+            if (!om) break;
+            const int fl = __ffsll((unsigned long long) om) - 1;
+            const uint64_t below = (1ull << fl) - 1ull;
+            x->cnt[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && lane < fl && rank == 0) x->cnt[d] = (uint32_t) __popcll(m & below);
+            __builtin_amdgcn_wave_barrier();
+            // the round that begins with record (row, fl)
+            k_cur++;
+            const unsigned long long nb = x->pos[lane] + x->cnt[lane];
+            if (k_cur == k_in + 1) first_nb = nb;
+            if ((uint32_t) lane < P) os_store_status(p.rt + (uint64_t) k_cur * P + lane, OS_RT_VALID | nb);
+            if (lane == 0) {
+                os_store_status(p.rt_start + k_cur, OS_RT_VALID | (t0 + (uint32_t) row * 64 + (uint32_t) fl));
+                atomicMax(&p.ctrl->head.rounds_cut, k_cur);
+            }
+            if (is_part) {
+                base = nb;
+                lim = nb + my_cap;
+                x->lim[lane] = lim;
+            }
+            __builtin_amdgcn_wave_barrier();
+            open &= ~below;
+            if (k_cur >= p.max_rounds) {
+                stop = true; // the end marker: nothing from here on is consumed
+                break;
+            }
+            // a record that does not fit an empty partition (src/collectiveshuffler.h:156-159)
+            const bool never = valid && lane == fl && x->pos[d] + rank >= x->lim[d];
+            if (__ballot(never)) {
+                raise_error(p.ctrl, MGS_ERR_RECORD_SIZE);
+                stop = true;
+                break;
+            }
+        }
+        if (valid && rank == 0) x->pos[d] += (unsigned long long) __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (!__ballot(is_part && acc + tot > lim)) stop = true; // no cut in what is left of the tile
+    }
+    }
+}
+
 // NB: number of destination bits (ceil(log2(P)), at least 1) as a constant, so
 // that the match-any loop and the search for a slot's destination unroll.
 //
@@ -314,8 +463,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
     __shared__ unsigned long long addr2[2 * OS_MAXP];           // see above, two tiles
     __shared__ unsigned long long pbase[OS_MAXP];
     __shared__ unsigned long long pcap[OS_MAXP];
-    __shared__ volatile uint32_t misc[4]; // [0] first tile, [1] next tile, [2+par] fits
+    __shared__ volatile uint32_t misc[8]; // [0] first tile, [1] next tile, [2+par] store mode,
+                                          // [4+par] / [6+par] first / last round of the tile
     __shared__ uint32_t arrive[2];        // worker waves done hashing, per tile parity
+    __shared__ OsCutLds cutlds;           // scan wave only, tiles that hold a round cut
+    __shared__ unsigned long long rb2[2 * 2 * OS_MAXP]; // per parity: totals at the first record of the tile's
+                                                        // first round and of the round after it (checked path)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr bool S_ND = (VAR & OSV_NODEST) != 0;
@@ -343,6 +496,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
         __builtin_amdgcn_s_setprio(3);
         OsWalkStats ws;
         const unsigned long long my_base = pbase[lane], my_cap = pcap[lane];
+        // round state, lane = destination: the round the previous tile ended in, the running
+        // totals at its first record and the totals at which its partitions are full
+        const bool is_part = (uint32_t) lane < P && lane != p.self, is_self = lane == p.self;
+        uint32_t k_cur = 0;
+        unsigned long long base = 0, lim = my_cap;
         while (tile < p.ntiles) {
             const uint32_t *wc = wcnt + par * CNT;
             __syncthreads(); // A: counts(tile) complete
@@ -371,11 +529,48 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
                     os_store_status(p.status + (uint64_t) tile * P + lane,
                                     OS_FLAG_INCL | ((acc + tot) & OS_VALUE_MASK));
             }
-            const bool over = (uint32_t) lane < P && acc + tot > my_cap;
-            const bool fits = __ballot(over) == 0;
+            // Which round does the tile start in?  Totals beyond a partition's limit mean that
+            // a cut lies before this tile: its round is in the table, or will be shortly.
+            if (!(VAR & OSV_FAKE_CHAIN) && k_cur < p.max_rounds) {
+                while (__ballot(is_part && acc > lim)) {
+                    k_cur++;
+                    const unsigned long long nb = os_rt_wait(p, k_cur, lane, (uint32_t) lane < P);
+                    if (is_part) {
+                        base = nb;
+                        lim = nb + my_cap;
+                    }
+                    if (k_cur >= p.max_rounds
+                        || __hip_atomic_load(&p.ctrl->head.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                        break;
+                }
+            }
+            // store mode: 1 = the tile lies inside one round and below every capacity (one
+            // table read per record), 0 = checked path (round cuts inside the tile, or the
+            // local stream runs full), 2 = the tile lies after the last round: not consumed
+            const uint32_t kfirst = k_cur;
+            uint32_t mode = 1;
+            if (VAR & OSV_FAKE_CHAIN) mode = 1;
+            else if (k_cur >= p.max_rounds) mode = 2;
+            else if (__ballot(is_part && acc + tot > lim)) {
+                unsigned long long first_nb = 0;
+                rb2[(par * 2 + 0) * OS_MAXP + lane] = base;
+                os_find_cuts16<NB, ITEMS>(p, tile, WORKERS, lane, acc, tot, wc, is_part, my_cap, k_cur, base, lim,
+                                          first_nb, &cutlds);
+                rb2[(par * 2 + 1) * OS_MAXP + lane] = first_nb;
+                mode = 0;
+            }
+            else if (__ballot(is_self && acc + tot > my_cap)) {
+                rb2[(par * 2 + 0) * OS_MAXP + lane] = base;
+                mode = 0;
+            }
             gpos2[par * OS_MAXP + lane] = acc;
-            addr2[par * OS_MAXP + lane] = my_base + ((acc - first_slot) << 4);
-            if (lane == 0) misc[2 + par] = fits ? 1u : 0u;
+            addr2[par * OS_MAXP + lane] =
+                my_base + (is_part ? (unsigned long long) kfirst * p.image_stride : 0ull) + ((acc - base - first_slot) << 4);
+            if (lane == 0) {
+                misc[2 + par] = mode;
+                misc[4 + par] = kfirst;
+                misc[6 + par] = k_cur;
+            }
             tile = next;
             par ^= 1;
         }
@@ -393,7 +588,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
     // 16-byte slots of one partition run.
     auto store_image = [&](uint32_t t, int pr) {
         const uint32_t total = binstart2[pr * (OS_MAXP + 4) + 64];
-        if (misc[2 + pr] != 0) {
+        const uint32_t mode = misc[2 + pr];
+        if (mode == 2) return; // after the last round: nothing of this tile is consumed
+        if (mode == 1) {
             const unsigned long long *addr = addr2 + pr * OS_MAXP;
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) {
@@ -414,25 +611,39 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
         }
         const uint32_t *binstart = binstart2 + pr * (OS_MAXP + 4);
         const unsigned long long *gpos = gpos2 + pr * OS_MAXP;
-        bool overflow = false;
-#pragma unroll
+        const uint32_t kfirst = misc[4 + pr], klast = misc[6 + pr];
+        (void) t;
+#pragma unroll 1
         for (int k = 0; k < ITEMS; k++) {
             const uint32_t s = (uint32_t) k * WTHREADS + tid;
             if (s < total) {
                 const uint32_t b = sdest[s];
-                const unsigned long long pos = gpos[b] + (s - binstart[b]);
-                if (pos < pcap[b]) {
-                    reinterpret_cast<uint4 *>(pbase[b])[pos] = srec[s];
-                }
-                else if ((int32_t) b == p.self) {
-                    raise_error(p.ctrl, MGS_ERR_LOCAL_OVERFLOW);
+                const unsigned long long g = gpos[b] + (s - binstart[b]); // units of b before this record
+                if ((int32_t) b == p.self) {
+                    if (g < pcap[b]) reinterpret_cast<uint4 *>(pbase[b])[g] = srec[s];
+                    else raise_error(p.ctrl, MGS_ERR_LOCAL_OVERFLOW);
                 }
                 else {
-                    overflow = true;
+                    // the record's round: the last one of the tile's rounds that begins at or before
+                    // it.  The first two are at hand in LDS (nearly every cut tile holds one cut);
+                    // a tile with more reads the round table.
+                    uint32_t kk = kfirst;
+                    unsigned long long bk = rb2[(pr * 2 + 0) * OS_MAXP + b];
+                    if (kk < klast && rb2[(pr * 2 + 1) * OS_MAXP + b] <= g) {
+                        bk = rb2[(pr * 2 + 1) * OS_MAXP + b];
+                        kk++;
+                        while (kk < klast) {
+                            const unsigned long long bn = os_load_status(p.rt + (uint64_t) (kk + 1) * P + b) & ~OS_RT_VALID;
+                            if (bn > g) break;
+                            bk = bn;
+                            kk++;
+                        }
+                    }
+                    if (kk < p.max_rounds && g - bk < pcap[b])
+                        reinterpret_cast<uint4 *>(pbase[b] + (unsigned long long) kk * p.image_stride)[g - bk] = srec[s];
                 }
             }
         }
-        if (overflow) atomicMin(&p.ctrl->head.cut_tile, t);
     };
 
     while (tile < p.ntiles) {
@@ -514,6 +725,70 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
     __syncthreads(); // image(prev) and position(prev) ready
     if (prev != 0xFFFFFFFFu) store_image(prev, par ^ 1);
     (void) nbits;
+}
+
+// Result table of a round-cutting call, 8-byte words, R = max_rounds:
+//   [0] rounds begun (<= R)   [1] first record not consumed (absolute index)
+//   [2] records packed into send images   [3] local-bypass records   [4] their bytes
+//   [8 + k]          index of the first record after round k (absolute)
+//   [8 + R + k]      local-bypass records emitted during round k
+//   [8 + 2R + k]     their bytes
+//   [8 + 3R + k*P + b]  bytes of partition b in image k (send_offset of that round)
+constexpr int OS_RTAB_HEAD = 8;
+__host__ __device__ inline size_t os_rtab_words(uint32_t max_rounds, uint32_t P)
+{
+    return (size_t) OS_RTAB_HEAD + (size_t) max_rounds * (3 + (size_t) P);
+}
+
+// Columns of the chained scan: PC of them, the first P count partition units of
+// 1 << unit_shift bytes; lrec_col counts local-bypass records (for 16-byte records the
+// local partition's own column, else an extra column).
+__global__ __launch_bounds__(256) void k_os_rounds_final(OsParams p, uint32_t P, uint32_t lrec_col,
+                                                         unsigned long long *tab)
+{
+    const uint32_t PC = p.P, R = p.max_rounds;
+    const uint32_t cuts = p.ctrl->head.rounds_cut;
+    const uint32_t n_rounds = cuts + 1 < R ? cuts + 1 : R;
+    const bool all = cuts < R; // every record was consumed
+    auto begin_of = [&](uint32_t k, uint32_t col) -> unsigned long long { // totals at the first record of round k
+        return k ? (p.rt[(uint64_t) k * PC + col] & ~OS_RT_VALID) : 0ull;
+    };
+    auto end_of = [&](uint32_t k, uint32_t col) -> unsigned long long { // totals at the end of round k
+        if (k + 1 <= cuts) return p.rt[(uint64_t) (k + 1) * PC + col] & ~OS_RT_VALID;
+        return p.status[(uint64_t) (p.ntiles - 1) * PC + col] & OS_VALUE_MASK;
+    };
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    for (uint64_t t = gtid; t < (uint64_t) n_rounds * (P + 1); t += gsz) {
+        const uint32_t k = (uint32_t) (t / (P + 1)), b = (uint32_t) (t % (P + 1));
+        if (b == P) {
+            const unsigned long long nx = (k + 1 <= cuts) ? (p.rt_start[k + 1] & ~OS_RT_VALID) : p.n;
+            tab[OS_RTAB_HEAD + k] = p.first + nx;
+            unsigned long long lrec = 0, lbytes = 0;
+            if (p.self >= 0) {
+                lrec = end_of(k, lrec_col) - begin_of(k, lrec_col);
+                lbytes = (end_of(k, (uint32_t) p.self) - begin_of(k, (uint32_t) p.self)) << p.unit_shift;
+            }
+            tab[OS_RTAB_HEAD + R + k] = lrec;
+            tab[OS_RTAB_HEAD + 2 * (uint64_t) R + k] = lbytes;
+        }
+        else {
+            const unsigned long long u = ((int32_t) b == p.self) ? 0ull : end_of(k, b) - begin_of(k, b);
+            tab[OS_RTAB_HEAD + 3 * (uint64_t) R + (uint64_t) k * P + b] = u << p.unit_shift;
+        }
+    }
+    if (gtid == 0) {
+        const unsigned long long nx = all ? p.n : (p.rt_start[R] & ~OS_RT_VALID);
+        unsigned long long lrec = 0, lbytes = 0;
+        if (p.self >= 0) {
+            lrec = end_of(n_rounds - 1, lrec_col);
+            lbytes = end_of(n_rounds - 1, (uint32_t) p.self) << p.unit_shift;
+        }
+        tab[0] = n_rounds;
+        tab[1] = p.first + nx;
+        tab[2] = nx - lrec;
+        tab[3] = lrec;
+        tab[4] = lbytes;
+    }
 }
 
 } // namespace mgs

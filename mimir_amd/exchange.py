@@ -86,3 +86,59 @@ def exchange_round(send_image, send_offset_host, buf_size, recv_image, done=Fals
     sent = [0] * P if done else [int(x) for x in send_offset_host]
     got = exchange_payload(send_image, sent, rc_host, buf_size, recv_image, group)
     return rc_host, done_count, got
+
+
+def exchange_rounds(send_images, image_stride, round_send_offset, buf_size, recv_images,
+                    recv_stride, group=None):
+    """The exchanges of a batch that was packed into many rounds at once
+    (DevicePacker.pack_rounds): round k of every rank is the k-th exchange_kv of the
+    reference (src/collectiveshuffler.h:587-674).  Ranks cut their rounds where their own
+    data says, so they hold different numbers of rounds; a rank that has run out takes
+    part in the remaining exchanges with empty partitions, as the reference's wait()
+    does (:528-561).
+
+    send_images      : uint8; image k at [k*image_stride :], partition d at d*buf_size
+    round_send_offset: host int64 array [R_mine, P]: bytes per partition and round
+    recv_images      : uint8; the receive image of exchange k is written at
+                       [k*recv_stride :], source 0's bytes, then source 1's, ...
+    The counts of all rounds travel in one all-to-all (one row per round) instead of one
+    per round; the payload goes round by round, each a grouped batch of point-to-point
+    transfers straight out of the send image.  Returns (recv_count int64 [R, P], R)."""
+    import numpy as np
+    P = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    dev = send_images.device
+    so = np.asarray(round_send_offset, dtype=np.int64).reshape(-1, P)
+    r_mine = so.shape[0]
+    rmax = torch.tensor([r_mine], dtype=torch.int64, device=dev)
+    dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group)
+    R = int(rmax.item())
+    full = np.zeros((R, P), dtype=np.int64)
+    full[:r_mine] = so
+    # counts: rank d gets column d of every rank's matrix
+    send = torch.from_numpy(np.ascontiguousarray(full.T)).to(dev)     # [P, R]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_count = recv.cpu().numpy().T.copy()                         # [R, P]: bytes from each source
+    works = []
+    for k in range(R):
+        ops, roff = [], k * recv_stride
+        for peer in range(P):
+            rc = int(recv_count[k, peer])
+            if rc > 0 and peer != me:
+                ops.append(dist.P2POp(dist.irecv, recv_images[roff:roff + rc],
+                                      dist.get_global_rank(group, peer) if group else peer, group=group))
+            roff += rc
+        for peer in range(P):
+            sb = int(full[k, peer])
+            if sb > 0 and peer != me:
+                o = k * image_stride + peer * buf_size
+                ops.append(dist.P2POp(dist.isend, send_images[o:o + sb],
+                                      dist.get_global_rank(group, peer) if group else peer, group=group))
+        if ops:
+            works.extend(dist.batch_isend_irecv(ops))
+    for w in works:
+        w.wait()
+    if send_images.is_cuda:
+        torch.cuda.current_stream(dev).synchronize()
+    return recv_count, R

@@ -31,6 +31,22 @@ class RoundResult:
                 f"send_offset={self.send_offset.tolist()})")
 
 
+class RoundsResult:
+    """Host copy of a many-round pack call: totals plus one row per round."""
+
+    def __init__(self, r, nxt, so, lrec, lbytes, nranks):
+        n = int(r.n_rounds)
+        self.n_rounds = n
+        self.next = int(r.next)
+        self.packed_records = int(r.packed_records)
+        self.local_records = int(r.local_records)
+        self.local_bytes = int(r.local_bytes)
+        self.round_next = nxt[:n].copy()
+        self.round_send_offset = so[:n * nranks].reshape(n, nranks).copy()
+        self.round_local_records = lrec[:n].copy()
+        self.round_local_bytes = lbytes[:n].copy()
+
+
 class DevicePacker:
     """One rank's pack state (mgs_handle) on one GPU.
 
@@ -127,6 +143,42 @@ class DevicePacker:
         r = capi.Round()
         self._check(self.lib.mgs_pack_device(*args, C.byref(r)))
         return RoundResult(r, self.nranks)
+
+    def _rounds_buffers(self, max_rounds):
+        return (np.zeros(max_rounds, dtype=np.uint64), np.zeros(max_rounds * self.nranks, dtype=np.int64),
+                np.zeros(max_rounds, dtype=np.uint64), np.zeros(max_rounds, dtype=np.int64))
+
+    def pack_rounds(self, records, n_end, send_images, image_stride, max_rounds, start=0, rec_off=None,
+                    init_offset=None, local_out=None, dest_out=None, algo=capi.ALGO_AUTO, stream=None):
+        """mgs_pack_rounds_device: records [start, n_end) into up to max_rounds send images
+        (image k at send_images[k * image_stride:]), round boundaries as the reference cuts them."""
+        args, _keep = self._args(records, rec_off, n_end, start, init_offset, send_images, local_out,
+                                 dest_out, algo, stream)
+        h, rec, off, n_end, start, init_p, img, loc, lcap, dst, algo, st = args
+        nxt, so, lrec, lbytes = self._rounds_buffers(max_rounds)
+        r = capi.Rounds()
+        self._check(self.lib.mgs_pack_rounds_device(
+            h, rec, off, n_end, start, init_p, img, image_stride, max_rounds, loc, lcap, dst, algo, st,
+            C.byref(r), nxt.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p),
+            lrec.ctypes.data_as(C.c_void_p), lbytes.ctypes.data_as(C.c_void_p)))
+        return RoundsResult(r, nxt, so, lrec, lbytes, self.nranks)
+
+    def pack_rounds_async(self, records, n_end, send_images, image_stride, max_rounds, start=0, rec_off=None,
+                          init_offset=None, local_out=None, dest_out=None, algo=capi.ALGO_AUTO, stream=None):
+        args, _keep = self._args(records, rec_off, n_end, start, init_offset, send_images, local_out,
+                                 dest_out, algo, stream)
+        h, rec, off, n_end, start, init_p, img, loc, lcap, dst, algo, st = args
+        self._pending_rounds = max_rounds
+        self._check(self.lib.mgs_pack_rounds_device_async(
+            h, rec, off, n_end, start, init_p, img, image_stride, max_rounds, loc, lcap, dst, algo, st))
+
+    def rounds_result(self):
+        nxt, so, lrec, lbytes = self._rounds_buffers(self._pending_rounds)
+        r = capi.Rounds()
+        self._check(self.lib.mgs_pack_rounds_result(
+            self.h, C.byref(r), nxt.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p),
+            lrec.ctypes.data_as(C.c_void_p), lbytes.ctypes.data_as(C.c_void_p)))
+        return RoundsResult(r, nxt, so, lrec, lbytes, self.nranks)
 
     def pack_noalloc(self, records, n_end, send_image, start=0, rec_off=None,
                      init_offset=None, local_out=None, dest_out=None, stream=None):

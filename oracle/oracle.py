@@ -197,7 +197,7 @@ class Oracle:
         return h, d
 
     def pack_round(self, lay, blob, rec_off, n, start, nranks, self_rank,
-                   buf_size, want_bytes=True):
+                   buf_size, want_bytes=True, init_offset=None):
         """One CollectiveShuffler::write round.  Returns a dict with next,
         send_offset[int64 P], partitions (list of bytes-like np arrays),
         local (np uint8), local_records, packed_records."""
@@ -209,7 +209,13 @@ class Oracle:
             (n - start) * lay.fixed_len())
         loc = np.zeros(max(total, 1), dtype=np.uint8) if want_bytes else None
         lb, lr, pr = C.c_int64(), C.c_uint64(), C.c_uint64()
-        nxt = self.L.mo_pack_round(
+        fn = self.L.mo_pack_round
+        if init_offset is not None:  # the round goes on from partly filled partitions
+            so[:] = np.asarray(init_offset, dtype=np.int64)[:nranks]
+            if self_rank >= 0:
+                so[self_rank] = 0
+            fn = self.L.mo_pack_more
+        nxt = fn(
             C.byref(lay), blob.ctypes.data,
             offs.ctypes.data if offs is not None else None,
             lay.fixed_len() or 0, n, start, nranks, self_rank, buf_size,

@@ -1,0 +1,166 @@
+"""Many rounds per call (mgs_pack_rounds_device) against the oracle driven round by
+round: every send image byte-identical to the oracle's send buffer of that round,
+the same round boundaries, the same local stream and per-round counters.  The
+16-byte layout cuts its rounds inside the one-sweep kernel; the others loop over
+one-round calls -- both must equal the reference's sequence of exchange_kv rounds
+(src/collectiveshuffler.h:131-166)."""
+import numpy as np
+import pytest
+
+from mimir_amd import capi, datagen
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_rounds(oracle, olay, blob, offs, n, P, rank, buf, start=0, init=None, max_rounds=1 << 30):
+    """The reference's rounds: pack until a record does not fit, exchange, go on."""
+    rounds, cur = [], start
+    while len(rounds) < max_rounds:
+        r = oracle.pack_round(olay, blob, offs, n, cur, P, rank, buf,
+                              init_offset=init if not rounds else None)
+        rounds.append(r)
+        cur = r["next"]
+        if cur >= n:
+            break
+    return rounds, cur
+
+
+def check_rounds(oracle, blob, offs, lay_t, n, P, rank, buf, max_rounds, start=0, init=None,
+                 stride_extra=0, expect_algo=None):
+    import torch
+    from mimir_amd.packer import DevicePacker
+    glay, olay = capi.Layout.make(*lay_t), O.Layout.make(*lay_t)
+    want, want_next = oracle_rounds(oracle, olay, blob, offs, n, P, rank, buf, start, init, max_rounds)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(np.ascontiguousarray(blob)).to(dev)
+    d_off = None if offs is None else torch.from_numpy(offs.astype(np.uint32).view(np.int32)).to(dev)
+    stride = P * buf + stride_extra
+    pk = DevicePacker(glay, P, rank, buf, max_records=max(n, 1))
+    images = torch.full((max_rounds * stride,), 0xEE, dtype=torch.uint8, device=dev)
+    local = torch.full((max(len(blob), 16),), 0xDD, dtype=torch.uint8, device=dev) if rank >= 0 else None
+    dest = torch.full((max(n - start, 1),), 0xFF, dtype=torch.uint8, device=dev)
+    got = pk.pack_rounds(d_blob, n, images, stride, max_rounds, start=start, rec_off=d_off,
+                         init_offset=init, local_out=local, dest_out=dest)
+    torch.cuda.synchronize()
+    if expect_algo:
+        assert pk.last_algo() == expect_algo
+    assert got.n_rounds == len(want), (got.n_rounds, len(want))
+    assert got.next == want_next
+    img = images.cpu().numpy()
+    loc = local.cpu().numpy() if rank >= 0 else None
+    lpos = 0
+    for k, w in enumerate(want):
+        assert int(got.round_next[k]) == w["next"], f"round {k}"
+        assert got.round_send_offset[k].tolist() == w["send_offset"].tolist(), f"round {k}"
+        assert int(got.round_local_records[k]) == w["local_records"], f"round {k}"
+        assert int(got.round_local_bytes[k]) == w["local_bytes"], f"round {k}"
+        for p in range(P):
+            so = int(w["send_offset"][p])
+            o = k * stride + p * buf
+            lo = int(init[p]) if (init is not None and k == 0 and p != rank) else 0
+            assert np.array_equal(img[o + lo:o + so], w["partitions"][p][lo:]), f"round {k} partition {p}"
+        if rank >= 0:
+            assert np.array_equal(loc[lpos:lpos + w["local_bytes"]], w["local"]), f"round {k} local stream"
+            lpos += w["local_bytes"]
+    assert got.local_bytes == lpos
+    assert got.packed_records == sum(w["packed_records"] for w in want)
+    assert got.local_records == sum(w["local_records"] for w in want)
+    _, d = oracle.dest(olay, blob, offs, n, P)
+    assert np.array_equal(dest.cpu().numpy()[:want_next - start].astype(np.int32), d[start:want_next])
+    # untouched bytes between images stay untouched
+    if stride_extra:
+        for k in range(max_rounds):
+            assert (img[k * stride + P * buf:(k + 1) * stride] == 0xEE).all()
+    pk.close()
+    return got
+
+
+@pytest.mark.parametrize("P,rank", [(8, -1), (8, 3), (2, 0), (3, 2), (5, -1), (64, 17), (1, -1)])
+def test_rounds_16_byte_records(oracle, P, rank):
+    n = 200_000
+    blob, offs, lay = datagen.u64_records(n, seed=100 + P)
+    buf = 16 * (n // P // 9)          # about ten rounds
+    got = check_rounds(oracle, blob, offs, lay, n, P, rank, buf, max_rounds=64, expect_algo="onesweep16")
+    assert got.n_rounds >= (2 if P == 1 else 8)
+
+
+@pytest.mark.parametrize("cap_records", [1, 2, 7, 63, 64, 65, 500, 3583, 3584, 3585])
+def test_rounds_tiny_and_tile_sized_partitions(oracle, cap_records):
+    """Many cuts inside one tile (3584 records), cuts on tile and row edges."""
+    n = 9000 if cap_records < 100 else 40_000
+    blob, offs, lay = datagen.u64_records(n, seed=7)
+    max_rounds = 4096 if cap_records < 8 else 700
+    check_rounds(oracle, blob, offs, lay, n, 4, 1, 16 * cap_records, max_rounds=max_rounds)
+
+
+def test_rounds_run_out(oracle):
+    """max_rounds smaller than the rounds of the batch: the call stops at a cut and the
+    next call goes on from there."""
+    n, P, rank = 150_000, 8, 5
+    blob, offs, lay = datagen.u64_records(n, seed=3)
+    buf = 16 * (n // P // 20)
+    got = check_rounds(oracle, blob, offs, lay, n, P, rank, buf, max_rounds=6)
+    assert got.n_rounds == 6 and got.next < n
+    got2 = check_rounds(oracle, blob, offs, lay, n, P, rank, buf, max_rounds=64, start=got.next)
+    assert got2.next == n
+    one = check_rounds(oracle, blob, offs, lay, n, P, rank, buf, max_rounds=1)
+    assert one.n_rounds == 1 and one.next == int(got.round_next[0])
+
+
+def test_rounds_with_initial_fill_and_padded_stride(oracle):
+    n, P, rank = 100_000, 4, -1
+    blob, offs, lay = datagen.u64_records(n, seed=11)
+    buf = 16 * 3000
+    init = np.array([16 * 2999, 0, 16 * 3000, 16 * 17], dtype=np.int64)  # one almost full, one full
+    check_rounds(oracle, blob, offs, lay, n, P, rank, buf, max_rounds=40, init=init, stride_extra=4096)
+
+
+def test_rounds_skewed_keys(oracle):
+    """One hot destination: rounds end while the other partitions are almost empty."""
+    n, P = 120_000, 8
+    rec = np.zeros((n, 2), dtype=np.uint64)
+    rng = np.random.default_rng(5)
+    hot = rng.random(n) < 0.8
+    rec[:, 0] = np.where(hot, 12345, rng.integers(0, 1 << 62, size=n, dtype=np.uint64))
+    rec[:, 1] = np.arange(n)
+    blob = rec.view(np.uint8).reshape(-1)
+    check_rounds(oracle, blob, None, (capi.KEY_FIXED, 8, capi.VAL_FIXED, 8), n, P, 2, 16 * 4000, max_rounds=64)
+
+
+@pytest.mark.parametrize("kind", ["words", "oct12", "join"])
+def test_rounds_other_layouts(oracle, kind):
+    n = 60_000
+    if kind == "words":
+        blob, offs, lay = datagen.word_records(n, n_unique=3000, alpha=1.0, len_mean=6, len_sd=1, seed=21)
+    elif kind == "oct12":
+        blob, offs, lay = datagen.octree_records(n, level=12, seed=22)
+    else:
+        blob, offs, lay = datagen.join_records(n, n_unique=2000, len_mean=6, len_sd=1, seed=23)
+    P, rank = 4, 1
+    buf = (len(blob) // P // 7) // 16 * 16
+    got = check_rounds(oracle, blob, offs, lay, n, P, rank, buf, max_rounds=64)
+    assert got.n_rounds >= 5
+
+
+def test_rounds_async_pair(oracle):
+    import torch
+    from mimir_amd.packer import DevicePacker
+    n, P = 300_000, 8
+    blob, _, lay = datagen.u64_records(n, seed=9)
+    buf = 16 * (n // P // 12)
+    pk = DevicePacker(capi.Layout.make(*lay), P, -1, buf, max_records=n)
+    d_blob = torch.from_numpy(blob).cuda()
+    images = torch.empty(40 * P * buf, dtype=torch.uint8, device="cuda:0")
+    want = pk.pack_rounds(d_blob, n, images, P * buf, 40)
+    ref_img = images.clone()
+    images.fill_(0)
+    pk.pack_rounds_async(d_blob, n, images, P * buf, 40)
+    got = pk.rounds_result()
+    assert got.n_rounds == want.n_rounds and got.next == want.next == n
+    assert np.array_equal(got.round_send_offset, want.round_send_offset)
+    for k in range(got.n_rounds):
+        for p in range(P):
+            o, so = k * P * buf + p * buf, int(got.round_send_offset[k][p])
+            assert torch.equal(images[o:o + so], ref_img[o:o + so])
+    pk.close()
