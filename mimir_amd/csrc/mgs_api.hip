@@ -15,6 +15,7 @@
 #include "mgs_onesweep16.h"
 #include "mgs_onesweep16w.h"
 #include "mgs_onesweepv.h"
+#include "mgs_onesweepd.h"
 #include "mgs_unpack.h"
 #include "mgs_tokenize.h"
 #include "mgs_group.h"
@@ -155,7 +156,17 @@ struct mgs_handle {
     size_t grp_bytes = 0;
     uint64_t *h_unp = nullptr;  // pinned: result + cuts
     bool pending_osv = false; // the byte-granular one-sweep path was enqueued (may have fallen back)
-    bool pending_noalloc = false; // ... through mgs_pack_device_noalloc: no generic kernels behind it
+    bool pending_noalloc = false; // ... through mgs_pack_device_noalloc: the generic kernels cannot take over
+    struct {                      // the call in flight, should the generic kernels have to redo it
+        const void *d_records;
+        const uint32_t *d_rec_off;
+        uint64_t n_end;
+        void *d_send_image, *d_local_out;
+        int64_t local_cap;
+        uint8_t *d_dest_out;
+    } redo = {};
+    bool ov_k_known = false;      // variable width: the record length has been looked at
+    uint32_t *h_probe = nullptr;  // pinned, two offsets
     int ov_k = 4;             // records per worker lane for variable-width input, adapted call by call
     int pending_ov_k = 4;
     // call in flight
@@ -283,6 +294,7 @@ void mgs_destroy(mgs_handle *h)
         if (h->d_unp) (void) hipFree(h->d_unp);
         if (h->d_grp) (void) hipFree(h->d_grp);
         if (h->h_unp) (void) hipHostFree(h->h_unp);
+        if (h->h_probe) (void) hipHostFree(h->h_probe);
         if (h->h_head) (void) hipHostFree(h->h_head);
         if (h->h_ctrl) (void) hipHostFree(h->h_ctrl);
         if (h->ev0) (void) hipEventDestroy(h->ev0);
@@ -366,6 +378,8 @@ int mgs_create(const mgs_desc *desc, mgs_handle **out)
         return fail(e, "hipHostMalloc(head)");
     if ((e = hipHostMalloc(&h->h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
         return fail(e, "hipHostMalloc(ctrl)");
+    if ((e = hipHostMalloc(&h->h_probe, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        return fail(e, "hipHostMalloc(probe)");
     *out = h;
     return MGS_OK;
 }
@@ -420,11 +434,28 @@ static int os16_min_tile()
 constexpr int kOvThreads = 512, kOvLanes = (kOvThreads / 64 - 1) * 64;
 static int ov_tile(int k) { return kOvLanes * k; }
 // largest K whose tile of `bytes_per_record`-byte records fits, 0 if none
-static int ov_pick_k(double bytes_per_record)
+static int ov_pick_k_legacy(double bytes_per_record)
 {
     for (int k = 4; k >= 1; k >>= 1)
         if ((double) ov_tile(k) * bytes_per_record + 15.0 <= (double) OV_IN_BYTES) return k;
     return 0;
+}
+// k_onesweepd: the 64*K records of a worker wave must fit its LDS slice
+static int od_pick_k(double bytes_per_record)
+{
+    for (int k = 4; k >= 1; k--)
+        if (64.0 * k * bytes_per_record + (double) OD_SLACK <= (double) OD_SB) return k;
+    return 0;
+}
+// MGS_OSV_LEGACY=1 runs the older byte-granular kernel (LDS image of the output), for A/B timing
+static bool osv_legacy()
+{
+    static const bool v = getenv("MGS_OSV_LEGACY") != nullptr && atoi(getenv("MGS_OSV_LEGACY")) != 0;
+    return v;
+}
+static int ov_pick_k(double bytes_per_record)
+{
+    return osv_legacy() ? ov_pick_k_legacy(bytes_per_record) : od_pick_k(bytes_per_record);
 }
 
 // Enqueue one pack call.  noalloc: the control block and the chained-scan arrays live
@@ -522,7 +553,18 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     // fixed widths a tile that fits the LDS staging buffer (variable widths are checked on the device)
     const bool ov_ok = P + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
                        && (h->fixed_len == 0 || ov_pick_k((double) h->fixed_len) != 0);
-    // variable width: K follows the record length seen in earlier calls (mgs_pack_result)
+    // variable width: K follows the record length seen in earlier calls (mgs_pack_result);
+    // the first call looks at the two ends of its offsets (two 4-byte copies, one wait)
+    if (h->fixed_len == 0 && !h->ov_k_known && ov_ok && (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEPV)) {
+        MGS_HIP(h, hipMemcpyAsync(&h->h_probe[0], d_rec_off + start, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        MGS_HIP(h, hipMemcpyAsync(&h->h_probe[1], d_rec_off + start + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        MGS_HIP(h, hipStreamSynchronize(stream));
+        if (h->h_probe[1] > h->h_probe[0]) {
+            const int k = ov_pick_k(1.25 * (double) (h->h_probe[1] - h->h_probe[0]) / (double) n);
+            h->ov_k = k ? k : 1;
+        }
+        h->ov_k_known = true;
+    }
     const int ov_k = h->fixed_len ? ov_pick_k((double) h->fixed_len) : h->ov_k;
     if (algo == MGS_ALGO_AUTO)
         algo = os_ok ? MGS_ALGO_ONESWEEP16 : (ov_ok ? MGS_ALGO_ONESWEEPV : MGS_ALGO_GENERIC);
@@ -644,12 +686,22 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     }
     else {
         const bool osv = algo == MGS_ALGO_ONESWEEPV;
-        // variable width without the generic kernels behind it: a tile that does not fit the
-        // staging buffer is reported as an error by mgs_pack_result
-        const bool may_fall_back = osv && h->fixed_len == 0 && !noalloc;
+        // variable width: a wave's records may be too long for its LDS slice; the one-sweep
+        // kernels then leave at once and the generic kernels enqueued behind them do the work.
+        // Without them behind (no-allocation call, several rounds) mgs_pack_result reports it.
         const bool check_spans = osv && h->fixed_len == 0;
+        const bool may_fall_back = false; // the generic kernels are enqueued by mgs_pack_result when needed
         h->pending_osv = osv;
+        if (!osv && max_rounds != 1) {
+            h->err = "the generic kernels pack one round per call";
+            return MGS_ERR_ARG;
+        }
         if (osv) {
+            const bool legacy = osv_legacy();
+            if (legacy && max_rounds != 1) {
+                h->err = "MGS_OSV_LEGACY packs one round per call";
+                return MGS_ERR_ARG;
+            }
             const int columns = P + (D.rank >= 0 ? 1 : 0);
             const int kOvTile = ov_tile(ov_k);
             int rc = scan_arrays(kOvTile, kOvTile, columns);
@@ -682,28 +734,64 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             c.ctrl = d_ctrl;
             MGS_HIP(h, hipMemsetAsync(d_status, 0, (size_t) c.ntiles * columns * sizeof(unsigned long long), stream));
             MGS_HIP(h, hipMemsetAsync(d_agg16, 0, ((size_t) c.ntiles << c.lpt_log) * sizeof(unsigned long long), stream));
-            if (check_spans)
-                hipLaunchKernelGGL(k_osv_check, dim3((c.ntiles + 255) / 256), dim3(256), 0, stream, q);
             const uint32_t grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2));
-            MGS_HIP(h, hipEventRecord(h->ev0, stream));
             const mgs_layout &L = D.layout;
-            const int lm = (L.val_kind == MGS_VAL_CSTR) ? 0 : (L.key_kind == MGS_KEY_CSTR ? 1 : 2);
+            // layout mode 1: ONE string key and a fixed-width or absent value
+            const int lm = (L.val_kind == MGS_VAL_CSTR) ? 0 : (L.key_kind == MGS_KEY_CSTR ? (L.key_count == 1 ? 1 : 0) : 2);
             typedef void (*OvKernel)(OvParams);
+            if (legacy) {
+                if (check_spans)
+                    hipLaunchKernelGGL(k_osv_check, dim3((c.ntiles + 255) / 256), dim3(256), 0, stream, q);
+                MGS_HIP(h, hipEventRecord(h->ev0, stream));
 #define OVK(K, V) {k_onesweepv<kOvThreads, K, V, 4, 8, 0>, k_onesweepv<kOvThreads, K, V, 4, 8, 1>, \
                    k_onesweepv<kOvThreads, K, V, 4, 8, 2>}
-            static const OvKernel kernels[7][3] = {OVK(1, 0), OVK(2, 0), OVK(4, 0), OVK(4, OSV_STATS),
-                                                   OVK(4, OSV_STATS | OSV_FAKE_CHAIN), OVK(4, OSV_NT_STORE),
-                                                   OVK(4, OSV_STATS | OSV_NT_STORE)};
+                static const OvKernel kernels[3][3] = {OVK(1, 0), OVK(2, 0), OVK(4, 0)};
 #undef OVK
-            // MGS_OSV_STATS: diagnostic build (K = 4 only), per-phase cycle counts in Ctrl::head.stats
-            // "2": also no chained scan, "3": no global stores and no counts, "4": counts without
-            // global stores (timing only, wrong output)
-            const char *sv = getenv("MGS_OSV_STATS");
-            const int ki = ov_k == 1 ? 0 : (ov_k == 2 ? 1 : (sv ? (atoi(sv) >= 2 && atoi(sv) <= 4 ? atoi(sv) + 2 : 3) : 2));
-            hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
+                const int ki = ov_k == 1 ? 0 : (ov_k == 2 ? 1 : 2);
+                hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
+                if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
+                hipLaunchKernelGGL(k_osv_finalize, dim3(1), dim3(64), 0, stream, q);
+            }
+            else {
+                // the direct kernel: round table + result table, as for 16-byte records
+                unsigned long long *d_tab = nullptr;
+                if (noalloc) {
+                    unsigned long long *base = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes);
+                    c.rt = base;
+                    d_tab = base + 2 * ((size_t) columns + 1);
+                }
+                else {
+                    rc = ensure_round_tables(h, max_rounds, columns, P);
+                    if (rc) return rc;
+                    c.rt = h->d_rt;
+                    d_tab = h->d_rtab;
+                }
+                c.rt_start = c.rt + ((size_t) max_rounds + 1) * columns;
+                c.max_rounds = max_rounds;
+                c.image_stride = (uint64_t) image_stride;
+                MGS_HIP(h, hipMemsetAsync(c.rt, 0, ((size_t) max_rounds + 1) * ((size_t) columns + 1) * sizeof(unsigned long long), stream));
+                if (check_spans) {
+                    const uint64_t items = (uint64_t) c.ntiles * (kOvThreads / 64 - 1);
+                    hipLaunchKernelGGL(k_osd_check, dim3((unsigned) ((items + 255) / 256)), dim3(256), 0, stream, q,
+                                       (uint32_t) (64 * ov_k), (uint32_t) (kOvThreads / 64 - 1));
+                }
+                MGS_HIP(h, hipEventRecord(h->ev0, stream));
+#define ODK(K, V) {k_onesweepd<kOvThreads, K, V, 4, 8, 0>, k_onesweepd<kOvThreads, K, V, 4, 8, 1>, \
+                   k_onesweepd<kOvThreads, K, V, 4, 8, 2>}
+                static const OvKernel kernels[5][3] = {ODK(1, 0), ODK(2, 0), ODK(3, 0), ODK(4, 0), ODK(4, OSV_FAKE_CHAIN)};
+#undef ODK
+                const char *sv = getenv("MGS_OSD_FAKECHAIN"); // timing only: no chained scan, wrong output
+                const int ki = (sv && atoi(sv) && ov_k == 4) ? 4 : ov_k - 1;
+                hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
+                if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
+                const size_t items = (size_t) max_rounds * ((size_t) P + 1);
+                hipLaunchKernelGGL(k_os_rounds_final, dim3((unsigned) std::min<size_t>(256, (items + 255) / 256)), dim3(256),
+                                   0, stream, c, (uint32_t) P, (uint32_t) P, d_tab);
+                MGS_HIP(h, hipMemcpyAsync(h->h_rtab, d_tab, os_rtab_words(max_rounds, (uint32_t) P) * sizeof(unsigned long long),
+                                          hipMemcpyDeviceToHost, stream));
+                h->pending_rounds = max_rounds;
+            }
             h->pending_ov_k = ov_k;
-            if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
-            hipLaunchKernelGGL(k_osv_finalize, dim3(1), dim3(64), 0, stream, q);
             h->last_algo = "onesweepv";
         }
         if (!osv || may_fall_back) {
@@ -738,6 +826,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     MGS_HIP(h, hipMemcpyAsync(h->h_ctrl, d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
     h->pending = true;
     h->pending_noalloc = noalloc;
+    h->redo = {d_records, d_rec_off, n_end, d_send_image, d_local_out, local_cap, d_dest_out};
     return MGS_OK;
 }
 
@@ -761,7 +850,12 @@ int mgs_pack_device_noalloc(mgs_handle *h, const void *d_records, const uint32_t
     return mgs_pack_result(h, out);
 }
 
-int mgs_pack_result(mgs_handle *h, mgs_round *out)
+static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller);
+
+int mgs_pack_result(mgs_handle *h, mgs_round *out) { return pack_result_impl(h, out, false); }
+
+// rounds_caller: mgs_pack_rounds_result reads the whole result table itself
+static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
 {
     if (!h || !out) return MGS_ERR_ARG;
     if (!h->pending) {
@@ -780,12 +874,25 @@ int mgs_pack_result(mgs_handle *h, mgs_round *out)
     MGS_HIP(h, hipStreamSynchronize(h->pending_stream));
     h->ev_valid = true;
     if (h->pending_osv && h->h_ctrl->head.fallback != 0) {
+        // records too long for the one-sweep kernel's LDS staging: it did nothing
         if (h->pending_noalloc) {
-            h->err = "mgs_pack_device_noalloc: a tile of records does not fit the kernel's LDS staging buffer "
+            h->err = "mgs_pack_device_noalloc: a wave's records do not fit the kernel's LDS staging buffer "
                      "(records too long); use mgs_pack_device";
             return MGS_ERR_RECORD_SIZE;
         }
-        h->last_algo = "generic"; // fell back on the device
+        if (h->pending_rounds > 1) {
+            h->err = "records too long for the one-sweep kernel's LDS staging: pack this batch round by round";
+            return MGS_ERR_RECORD_SIZE;
+        }
+        if (h->ov_k > 1) h->ov_k--; // the next call tries a smaller tile
+        // the generic kernels redo the call (same stream, same arguments)
+        int64_t init[MGS_MAX_RANKS];
+        memcpy(init, h->pending_init, sizeof(init));
+        const int rc = pack_enqueue(h, h->redo.d_records, h->redo.d_rec_off, h->redo.n_end, h->pending_start, init,
+                                    h->redo.d_send_image, h->redo.d_local_out, h->redo.local_cap, h->redo.d_dest_out,
+                                    MGS_ALGO_GENERIC, h->pending_stream, false);
+        if (rc) return rc;
+        return pack_result_impl(h, out, false);
     }
     const int derr = h->h_ctrl->head.error;
     if (derr != 0) {
@@ -810,7 +917,7 @@ int mgs_pack_result(mgs_handle *h, mgs_round *out)
         out->local_records = tab[3];
         out->local_bytes = (int64_t) tab[4];
         for (int b = 0; b < P; b++) out->send_offset[b] = (int64_t) tab[OS_RTAB_HEAD + 3 * R + b];
-        if (R != 1) {
+        if (R != 1 && !rounds_caller) {
             h->err = "mgs_pack_result: the call in flight packs several rounds (use mgs_pack_rounds_result)";
             return MGS_ERR_STATE;
         }
@@ -830,9 +937,7 @@ int mgs_pack_result(mgs_handle *h, mgs_round *out)
             const int k = ov_pick_k(1.25 * (double) bytes / (double) recs);
             h->ov_k = k ? k : 1;
         }
-        else if (h->pending_osv && h->h_ctrl->head.fallback != 0 && h->ov_k > 1) {
-            h->ov_k /= 2;
-        }
+
     }
     return MGS_OK;
 }
@@ -849,18 +954,24 @@ int mgs_pack_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_
 }
 
 // ---- many rounds per call ------------------------------------------------------------
-static bool rounds_in_kernel(const mgs_handle *h, const void *d_records, void *d_send_images, int64_t image_stride,
-                             void *d_local_out, const int64_t *init_offset, int algo)
+// Which kernel cuts the rounds of this call itself?  MGS_ALGO_ONESWEEP16 / MGS_ALGO_ONESWEEPV
+// (same conditions as in pack_enqueue), or 0: one kernel sequence per round.
+static int rounds_in_kernel(const mgs_handle *h, const void *d_records, void *d_send_images, int64_t image_stride,
+                            void *d_local_out, const int64_t *init_offset, int algo)
 {
-    // the 16-byte one-sweep kernel cuts rounds itself (same conditions as in pack_enqueue)
     const mgs_desc &D = h->desc;
-    bool ok = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEP16) && kOsVariants[h->os_variant].agg16
-              && h->fixed_len == 16 && D.nranks <= OS_MAXP && D.layout.key_kind == MGS_KEY_FIXED
-              && D.layout.key_bytes <= 16 && (D.buf_size % 16) == 0 && ((uintptr_t) d_records % 16) == 0
-              && ((uintptr_t) d_send_images % 16) == 0 && (image_stride % 16) == 0
-              && (D.rank < 0 || ((uintptr_t) d_local_out % 16) == 0);
-    for (int b = 0; b < D.nranks && ok && init_offset; b++) ok = (init_offset[b] % 16) == 0;
-    return ok;
+    bool os16 = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEP16) && kOsVariants[h->os_variant].agg16
+                && h->fixed_len == 16 && D.nranks <= OS_MAXP && D.layout.key_kind == MGS_KEY_FIXED
+                && D.layout.key_bytes <= 16 && (D.buf_size % 16) == 0 && ((uintptr_t) d_records % 16) == 0
+                && ((uintptr_t) d_send_images % 16) == 0 && (image_stride % 16) == 0
+                && (D.rank < 0 || ((uintptr_t) d_local_out % 16) == 0);
+    for (int b = 0; b < D.nranks && os16 && init_offset; b++) os16 = (init_offset[b] % 16) == 0;
+    if (os16) return MGS_ALGO_ONESWEEP16;
+    if (algo == MGS_ALGO_ONESWEEP16) return 0;
+    const bool osd = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEPV) && !osv_legacy()
+                     && D.nranks + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
+                     && (h->fixed_len == 0 || od_pick_k((double) h->fixed_len) != 0);
+    return osd ? MGS_ALGO_ONESWEEPV : 0;
 }
 
 int mgs_pack_rounds_device_async(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
@@ -873,13 +984,14 @@ int mgs_pack_rounds_device_async(mgs_handle *h, const void *d_records, const uin
         h->err = "mgs_pack_rounds_device: max_rounds >= 1 and image_stride >= nranks * buf_size required";
         return MGS_ERR_ARG;
     }
-    if (!rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo)) {
-        h->err = "mgs_pack_rounds_device_async: this layout packs one round per kernel sequence; use the "
-                 "blocking mgs_pack_rounds_device";
+    const int in_kernel = rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo);
+    if (!in_kernel) {
+        h->err = "mgs_pack_rounds_device_async: this layout / rank count packs one round per kernel sequence; "
+                 "use the blocking mgs_pack_rounds_device";
         return MGS_ERR_ARG;
     }
     return pack_enqueue(h, d_records, d_rec_off, n_end, start, init_offset, d_send_images, d_local_out, local_cap,
-                        d_dest_out, MGS_ALGO_ONESWEEP16, stream, false, max_rounds, image_stride);
+                        d_dest_out, in_kernel, stream, false, max_rounds, image_stride);
 }
 
 int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next, int64_t *round_send_offset,
@@ -908,10 +1020,22 @@ int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next,
         h->err = "mgs_pack_rounds_result: the call in flight is a one-round call (use mgs_pack_result)";
         return MGS_ERR_STATE;
     }
-    h->pending_rounds = 1; // mgs_pack_result checks errors and reads round 0
-    mgs_round r0;
-    const int rc = mgs_pack_result(h, &r0);
+    mgs_round r0; // errors, and round 0
+    const int rc = pack_result_impl(h, &r0, true);
     if (rc) return rc;
+    if (h->pending_rounds == 0) { // a one-round call that the generic kernels had to redo
+        out->n_rounds = 1;
+        out->next = r0.next;
+        out->packed_records = r0.packed_records;
+        out->local_records = r0.local_records;
+        out->local_bytes = r0.local_bytes;
+        if (round_next) round_next[0] = r0.next;
+        if (round_local_records) round_local_records[0] = r0.local_records;
+        if (round_local_bytes) round_local_bytes[0] = r0.local_bytes;
+        if (round_send_offset)
+            for (int b = 0; b < P; b++) round_send_offset[b] = r0.send_offset[b];
+        return MGS_OK;
+    }
     const unsigned long long *tab = h->h_rtab;
     out->n_rounds = (uint32_t) tab[0];
     out->next = tab[1];
@@ -941,11 +1065,15 @@ int mgs_pack_rounds_device(mgs_handle *h, const void *d_records, const uint32_t 
         return MGS_ERR_ARG;
     }
     if (rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo)) {
-        const int rc = mgs_pack_rounds_device_async(h, d_records, d_rec_off, n_end, start, init_offset, d_send_images,
-                                                    image_stride, max_rounds, d_local_out, local_cap, d_dest_out, algo,
-                                                    stream);
+        int rc = mgs_pack_rounds_device_async(h, d_records, d_rec_off, n_end, start, init_offset, d_send_images,
+                                              image_stride, max_rounds, d_local_out, local_cap, d_dest_out, algo,
+                                              stream);
         if (rc) return rc;
-        return mgs_pack_rounds_result(h, out, round_next, round_send_offset, round_local_records, round_local_bytes);
+        rc = mgs_pack_rounds_result(h, out, round_next, round_send_offset, round_local_records, round_local_bytes);
+        // variable-width records too long for the one-sweep kernel's staging: the generic
+        // kernels, one round per call
+        if (!(rc == MGS_ERR_RECORD_SIZE && h->pending_osv && h->h_ctrl->head.fallback != 0)) return rc;
+        algo = MGS_ALGO_GENERIC;
     }
     // Kernels that pack one round per launch sequence: one call per round (more when a
     // round outlasts the handle's max_records), the local stream and the destination

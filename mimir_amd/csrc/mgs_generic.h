@@ -65,27 +65,25 @@ __device__ __forceinline__ void gen_span(const GenParams &p, uint64_t i,
 __device__ inline bool gen_key_len(const mgs_layout &lay, const uint8_t *r,
                                    uint32_t len, uint32_t &klen)
 {
-    if (lay.key_kind == MGS_KEY_FIXED) {
-        klen = (uint32_t) lay.key_bytes;
-        if (lay.val_kind == MGS_VAL_CSTR) return klen < len && r[len - 1] == 0;
-        return true; // len == key_bytes + val_bytes by construction
-    }
-    if (lay.val_kind != MGS_VAL_CSTR) {
-        const uint32_t vlen =
-            (lay.val_kind == MGS_VAL_FIXED) ? (uint32_t) lay.val_bytes : 0u;
-        if (len < vlen + 1) return false;
-        klen = len - vlen;
-        return r[klen - 1] == 0;
-    }
-    // both halves are strings: the key ends after its key_count-th NUL
-    uint32_t pos = 0;
-    for (int s = 0; s < lay.key_count; s++) {
-        while (pos < len && r[pos] != 0) pos++;
-        if (pos >= len) return false;
-        pos++;
-    }
-    klen = pos;
-    return pos < len && r[len - 1] == 0;
+    // the bytes of `count` C strings with their NULs, starting at r[from]; ~0u: they do not end inside the record
+    auto strings = [&](uint32_t from, int count) -> uint32_t {
+        uint32_t pos = from;
+        for (int s = 0; s < (count > 0 ? count : 1); s++) {
+            while (pos < len && r[pos] != 0) pos++;
+            if (pos >= len) return ~0u;
+            pos++;
+        }
+        return pos - from;
+    };
+    if (lay.key_kind == MGS_KEY_FIXED) klen = (uint32_t) lay.key_bytes;
+    else klen = strings(0, lay.key_count);
+    if (klen == ~0u || klen > len) return false;
+    uint32_t vlen = 0;
+    if (lay.val_kind == MGS_VAL_FIXED) vlen = (uint32_t) lay.val_bytes;
+    else if (lay.val_kind == MGS_VAL_CSTR) vlen = strings(klen, lay.val_count);
+    // key and value are the whole record: a string key's first NUL(s) end it, nothing
+    // may follow the value
+    return vlen != ~0u && klen + vlen == len;
 }
 
 __global__ __launch_bounds__(GEN_THREADS) void k_gen_hist(GenParams p)

@@ -122,25 +122,7 @@ __device__ __forceinline__ uint32_t ov_hash_lds(const uint8_t *base, uint32_t of
 // Key length of one wire-form record held in LDS (same rules as gen_key_len).
 __device__ __forceinline__ bool ov_key_len(const mgs_layout &lay, const uint8_t *r, uint32_t len, uint32_t &klen)
 {
-    if (lay.key_kind == MGS_KEY_FIXED) {
-        klen = (uint32_t) lay.key_bytes;
-        if (lay.val_kind == MGS_VAL_CSTR) return klen < len && r[len - 1] == 0;
-        return klen <= len;
-    }
-    if (lay.val_kind != MGS_VAL_CSTR) {
-        const uint32_t vlen = (lay.val_kind == MGS_VAL_FIXED) ? (uint32_t) lay.val_bytes : 0u;
-        if (len < vlen + 1) return false;
-        klen = len - vlen;
-        return r[klen - 1] == 0;
-    }
-    uint32_t pos = 0;
-    for (int s = 0; s < lay.key_count; s++) {
-        while (pos < len && r[pos] != 0) pos++;
-        if (pos >= len) return false;
-        pos++;
-    }
-    klen = pos;
-    return pos < len && r[len - 1] == 0;
+    return gen_key_len(lay, r, len, klen);
 }
 
 // LDS -> LDS copy of len bytes, both sides at any alignment.

@@ -358,8 +358,10 @@ def test_onesweepv_string_values_and_join(oracle):
 
 
 def test_onesweepv_adapts_tile_to_record_length(oracle):
-    """Records too long for the default tile: the first call falls back, the next
-    calls on the same handle use a smaller tile.  Same bytes either way."""
+    """The tile follows the record length: the first call on a handle looks at the ends of
+    its offsets, later calls at what the call before saw.  A batch whose records are much
+    longer than the last one's falls back to the generic kernels once, the next call uses
+    a smaller tile.  Same bytes either way."""
     torch = _torch()
     from mimir_amd.packer import DevicePacker
     n = 30000
@@ -370,6 +372,13 @@ def test_onesweepv_adapts_tile_to_record_length(oracle):
     d_blob = torch.from_numpy(np.ascontiguousarray(blob)).cuda()
     d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
     pk = DevicePacker(glay, 8, 2, total, n)
+    # short records first: the handle settles on its largest tile
+    sblob, soffs, _ = datagen.join_records(n, n_unique=500, alpha=1.0, len_mean=2, len_sd=0, seed=47)
+    simage = torch.empty(8 * total, dtype=torch.uint8, device="cuda:0")
+    slocal = torch.empty(total, dtype=torch.uint8, device="cuda:0")
+    pk.pack(torch.from_numpy(np.ascontiguousarray(sblob)).cuda(), n, simage,
+            rec_off=torch.from_numpy(soffs.astype(np.uint32).view(np.int32)).cuda(), local_out=slocal)
+    assert pk.last_algo() == "onesweepv"
     algos = []
     for _ in range(3):
         image = torch.full((8 * total,), 0xEE, dtype=torch.uint8, device="cuda:0")
@@ -546,3 +555,68 @@ def test_full_size_properties(oracle):
     wrap = lambda x: (x + (1 << 63)) % (1 << 64) - (1 << 63)
     assert wrap(ksum) == wrap(total_key) and wrap(vsum) == wrap(total_val)
     pk.close()
+
+
+@pytest.mark.parametrize("algo", [capi.ALGO_GENERIC, capi.ALGO_ONESWEEPV])
+@pytest.mark.parametrize("bad", ["embedded_nul", "embedded_nul_long_key", "zero_length", "no_nul", "trailing_byte"])
+def test_malformed_records_are_refused_like_the_oracle(oracle, algo, bad):
+    """A record that is not a serialisation of the layout: the oracle's key-length rule
+    (strlen + 1 for a char* key, key and value are the whole record) refuses it, and so
+    does every kernel path -- the same records, not only the well-formed ones, decide."""
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    val = (1).to_bytes(8, "little")
+    good = [b"alpha\0" + val, b"be\0" + val, b"gamma-delta-epsilon\0" + val] * 400
+    bad_rec = {"embedded_nul": b"ab\0cd\0" + val,
+               "embedded_nul_long_key": b"abcdefghijklmnop\0qrstuv\0" + val,
+               "zero_length": b"",
+               "no_nul": b"abcdef" + val,
+               "trailing_byte": b"ab\0" + val + b"x"}[bad]
+    for where in (0, 700, len(good)):
+        recs = good[:where] + [bad_rec] + good[where:]
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+        blob = np.frombuffer(b"".join(recs), dtype=np.uint8).copy()
+        lay_t = (capi.KEY_CSTR, 0, capi.VAL_FIXED, 8)
+        glay, olay = _layouts(lay_t)
+        n = len(recs)
+        with pytest.raises(ValueError):
+            oracle.pack_round(olay, blob, offs, n, 0, 4, 1, 1 << 20)
+        pk = DevicePacker(glay, 4, 1, 1 << 20, n)
+        image = torch.empty(4 << 20, dtype=torch.uint8, device="cuda:0")
+        local = torch.empty(1 << 20, dtype=torch.uint8, device="cuda:0")
+        d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+        with pytest.raises(capi.MgsError) as ei:
+            pk.pack(torch.from_numpy(blob).cuda(), n, image, rec_off=d_off, local_out=local, algo=algo)
+        assert ei.value.status == capi.ERR_MALFORMED, (bad, where, pk.last_algo())
+        pk.close()
+
+
+def test_two_string_keys_with_fixed_value(oracle):
+    """keycount = 2 of char* with a fixed-width value: the key holds two NULs
+    (bytestream<char*>::size sums strlen + 1 over the strings, src/serializer.h:193-198)."""
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(5000):
+        a = bytes(rng.integers(97, 123, size=rng.integers(1, 6), dtype=np.uint8))
+        b = bytes(rng.integers(97, 123, size=rng.integers(0, 5), dtype=np.uint8))
+        recs.append(a + b"\0" + b + b"\0" + int(i).to_bytes(8, "little"))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    blob = np.frombuffer(b"".join(recs), dtype=np.uint8).copy()
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    glay = capi.Layout.make(capi.KEY_CSTR, 0, capi.VAL_FIXED, 8, key_count=2)
+    olay = O.Layout.make(capi.KEY_CSTR, 0, capi.VAL_FIXED, 8, key_count=2)
+    n, P, rank, buf = len(recs), 4, 2, 20000
+    want = oracle.pack_round(olay, blob, offs, n, 0, P, rank, buf)
+    for algo in (capi.ALGO_GENERIC, capi.ALGO_ONESWEEPV):
+        pk = DevicePacker(glay, P, rank, buf, n)
+        image = torch.empty(P * buf, dtype=torch.uint8, device="cuda:0")
+        local = torch.empty(len(blob), dtype=torch.uint8, device="cuda:0")
+        d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+        got = pk.pack(torch.from_numpy(blob).cuda(), n, image, rec_off=d_off, local_out=local, algo=algo)
+        assert got.next == want["next"] and got.send_offset.tolist() == want["send_offset"].tolist()
+        img = image.cpu().numpy()
+        for p in range(P):
+            so = int(want["send_offset"][p])
+            assert np.array_equal(img[p * buf:p * buf + so], want["partitions"][p])
+        pk.close()
