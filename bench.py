@@ -311,7 +311,7 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = n * world * args.steps / dt
-    in_kernel = pk.last_algo() == "onesweep16" or max_rounds == 1 or stats["rounds"] == 1
+    in_kernel = pk.last_algo() in ("onesweep16", "onesweepd") or max_rounds == 1 or stats["rounds"] == 1
     # one kernel covers the step (16-byte records cut their rounds inside the kernel); the
     # other layouts run one kernel sequence per round: price the pack calls' wall time then
     k_ms = sum(kernel_ms) / len(kernel_ms) if in_kernel else sum(pack_s) / len(pack_s) * 1e3
@@ -319,7 +319,7 @@ def main():
     kname = pk.tuning_name() if pk.last_algo() == "onesweep16" else pk.last_algo()
     # variant names start with the kernel family's letter (t = the plain kernel)
     kernel = {"onesweep16": "k_onesweep16" + ("<" if kname.startswith("t") else kname[:1]),
-              "onesweepv": "k_onesweepv", "generic": "k_gen_scatter"}[pk.last_algo()]
+              "onesweepv": "k_onesweepv", "onesweepd": "k_onesweepd", "generic": "k_gen_scatter"}[pk.last_algo()]
     if not in_kernel:
         kernel += f" x {stats['rounds']} rounds (one kernel sequence per round; wall time of the pack calls)"
     out = {

@@ -90,9 +90,18 @@ typedef struct mgs_desc {
     int64_t buf_size;     /* bytes per destination partition; send image is
                              nranks*buf_size (src/collectiveshuffler.h:46)   */
     int32_t device;       /* HIP device ordinal                              */
-    int32_t reserved;
+    int32_t flags;        /* 0, or MGS_FLAG_* below                          */
     uint64_t max_records; /* most records one mgs_pack_device call covers    */
 } mgs_desc;
+
+/* mgs_desc.flags: which of the two byte-granular one-sweep kernels
+ * MGS_ALGO_ONESWEEPV runs.  Default (0): one-round calls take the kernel that
+ * regroups a tile in LDS and stores whole aligned lines (faster for a single
+ * round), calls that cut several rounds take the kernel that cuts them itself.
+ * The flags pin one of them for every call (measurement, tests); the
+ * LDS-image kernel packs one round per call. */
+#define MGS_FLAG_OSV_ROUNDS_KERNEL 1
+#define MGS_FLAG_OSV_IMAGE_KERNEL 2
 
 typedef struct mgs_handle mgs_handle;
 

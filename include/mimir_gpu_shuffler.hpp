@@ -591,13 +591,24 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
                     a2av_token += 1;
                 }
             }
-            if (m->state == ShuffleMsgPending && this->comm->test(m->a2av_req)) {
+            // Rounds reach `out` in the order they were sent: an exchange that has completed
+            // waits for the ones started before it.  (The reference hands them over in
+            // buffer-index order, :362-383, so two rounds of one source can swap when both
+            // complete between two polls; a deterministic order costs nothing here.)
+            if (m->state == ShuffleMsgPending && oldest_pending(m) && this->comm->test(m->a2av_req)) {
                 save_data(m);
                 reset(m);
                 m->state = ShuffleMsgComplete;
                 pending_msg -= 1;
             }
         }
+    }
+
+    bool oldest_pending(const MsgBuf *m) const
+    {
+        for (size_t k = 0; k < msg.size(); k++)
+            if (msg[k]->state == ShuffleMsgPending && msg[k]->token < m->token) return false;
+        return true;
     }
 
     void save_data(MsgBuf *m) // :400-424

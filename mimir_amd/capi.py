@@ -15,6 +15,7 @@ KEY_FIXED, KEY_CSTR = 0, 1
 VAL_VOID, VAL_FIXED, VAL_CSTR = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_ONESWEEP16, ALGO_ONESWEEPV = 0, 1, 2, 3
 COMBINE_SUM_U64, COMBINE_MIN_U64, COMBINE_MAX_U64 = 0, 1, 2
+FLAG_OSV_ROUNDS_KERNEL, FLAG_OSV_IMAGE_KERNEL = 1, 2
 
 OK = 0
 ERR_ARG, ERR_HIP, ERR_RECORD_SIZE, ERR_LOCAL_OVERFLOW = -1, -2, -3, -4
@@ -48,7 +49,7 @@ class Layout(C.Structure):
 class Desc(C.Structure):
     _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32),
                 ("layout", Layout), ("buf_size", C.c_int64),
-                ("device", C.c_int32), ("reserved", C.c_int32),
+                ("device", C.c_int32), ("flags", C.c_int32),
                 ("max_records", C.c_uint64)]
 
 

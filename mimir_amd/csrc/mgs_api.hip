@@ -167,7 +167,9 @@ struct mgs_handle {
     } redo = {};
     bool ov_k_known = false;      // variable width: the record length has been looked at
     uint32_t *h_probe = nullptr;  // pinned, two offsets
-    int ov_k = 4;             // records per worker lane for variable-width input, adapted call by call
+    int ov_k = 4;             // (unused) records per worker lane of the last variable-width call
+    double ov_bytes_per_record = 16.0; // variable width: average record length seen last
+    int ov_shrink = 0;        // ... and how much smaller than that length suggests the tile must be
     int pending_ov_k = 4;
     // call in flight
     bool pending = false;
@@ -447,15 +449,21 @@ static int od_pick_k(double bytes_per_record)
         if (64.0 * k * bytes_per_record + (double) OD_SLACK <= (double) OD_SB) return k;
     return 0;
 }
-// MGS_OSV_LEGACY=1 runs the older byte-granular kernel (LDS image of the output), for A/B timing
-static bool osv_legacy()
+// Which byte-granular one-sweep kernel serves a call of `max_rounds` rounds: the LDS-image
+// kernel (k_onesweepv: one round per call, faster for it) or the round-cutting kernel
+// (k_onesweepd).  mgs_desc.flags pins one; MGS_OSV_LEGACY=1 / 0 in the environment does the
+// same for every handle (A/B timing).
+static bool osv_image_kernel(const mgs_handle *h, uint32_t max_rounds)
 {
-    static const bool v = getenv("MGS_OSV_LEGACY") != nullptr && atoi(getenv("MGS_OSV_LEGACY")) != 0;
-    return v;
+    static const char *env = getenv("MGS_OSV_LEGACY");
+    if (env) return atoi(env) != 0;
+    if (h->desc.flags & MGS_FLAG_OSV_IMAGE_KERNEL) return true;
+    if (h->desc.flags & MGS_FLAG_OSV_ROUNDS_KERNEL) return false;
+    return max_rounds == 1;
 }
-static int ov_pick_k(double bytes_per_record)
+static int ov_pick_k(bool image_kernel, double bytes_per_record)
 {
-    return osv_legacy() ? ov_pick_k_legacy(bytes_per_record) : od_pick_k(bytes_per_record);
+    return image_kernel ? ov_pick_k_legacy(bytes_per_record) : od_pick_k(bytes_per_record);
 }
 
 // Enqueue one pack call.  noalloc: the control block and the chained-scan arrays live
@@ -551,8 +559,9 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     for (int b = 0; b < P && os_ok; b++) os_ok = (h->pending_init[b] % 16) == 0;
     // byte-granular one-sweep: chain columns = P (+1 for the local record count) <= 64, and for
     // fixed widths a tile that fits the LDS staging buffer (variable widths are checked on the device)
+    const bool image_kernel = osv_image_kernel(h, max_rounds) && !noalloc;
     const bool ov_ok = P + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
-                       && (h->fixed_len == 0 || ov_pick_k((double) h->fixed_len) != 0);
+                       && (h->fixed_len == 0 || ov_pick_k(image_kernel, (double) h->fixed_len) != 0);
     // variable width: K follows the record length seen in earlier calls (mgs_pack_result);
     // the first call looks at the two ends of its offsets (two 4-byte copies, one wait)
     if (h->fixed_len == 0 && !h->ov_k_known && ov_ok && (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEPV)) {
@@ -560,12 +569,15 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         MGS_HIP(h, hipMemcpyAsync(&h->h_probe[1], d_rec_off + start + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         MGS_HIP(h, hipStreamSynchronize(stream));
         if (h->h_probe[1] > h->h_probe[0]) {
-            const int k = ov_pick_k(1.25 * (double) (h->h_probe[1] - h->h_probe[0]) / (double) n);
-            h->ov_k = k ? k : 1;
+            h->ov_bytes_per_record = (double) (h->h_probe[1] - h->h_probe[0]) / (double) n;
         }
         h->ov_k_known = true;
     }
-    const int ov_k = h->fixed_len ? ov_pick_k((double) h->fixed_len) : h->ov_k;
+    int ov_k = ov_pick_k(image_kernel, h->fixed_len ? (double) h->fixed_len : 1.25 * h->ov_bytes_per_record);
+    if (ov_k == 0) ov_k = 1;
+    if (h->fixed_len == 0 && h->ov_shrink > 0) // the LDS-image kernel exists for K = 4, 2, 1 only
+        ov_k = image_kernel ? std::max(1, ov_k >> std::min(h->ov_shrink, 2)) : std::max(1, ov_k - h->ov_shrink);
+    if (image_kernel && ov_k == 3) ov_k = 2;
     if (algo == MGS_ALGO_AUTO)
         algo = os_ok ? MGS_ALGO_ONESWEEP16 : (ov_ok ? MGS_ALGO_ONESWEEPV : MGS_ALGO_GENERIC);
     if (noalloc && algo == MGS_ALGO_GENERIC) {
@@ -697,9 +709,9 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             return MGS_ERR_ARG;
         }
         if (osv) {
-            const bool legacy = osv_legacy();
+            const bool legacy = image_kernel;
             if (legacy && max_rounds != 1) {
-                h->err = "MGS_OSV_LEGACY packs one round per call";
+                h->err = "the LDS-image kernel packs one round per call";
                 return MGS_ERR_ARG;
             }
             const int columns = P + (D.rank >= 0 ? 1 : 0);
@@ -776,12 +788,37 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                                        (uint32_t) (64 * ov_k), (uint32_t) (kOvThreads / 64 - 1));
                 }
                 MGS_HIP(h, hipEventRecord(h->ev0, stream));
-#define ODK(K, V) {k_onesweepd<kOvThreads, K, V, 4, 8, 0>, k_onesweepd<kOvThreads, K, V, 4, 8, 1>, \
-                   k_onesweepd<kOvThreads, K, V, 4, 8, 2>}
-                static const OvKernel kernels[5][3] = {ODK(1, 0), ODK(2, 0), ODK(3, 0), ODK(4, 0), ODK(4, OSV_FAKE_CHAIN)};
+#define ODKL(K, V, L) {k_onesweepd<kOvThreads, K, V, 4, L, 0>, k_onesweepd<kOvThreads, K, V, 4, L, 1>, \
+                       k_onesweepd<kOvThreads, K, V, 4, L, 2>}
+#define ODK(K, V) ODKL(K, V, 8)
+                static const OvKernel kernels[25][3] = {ODK(1, 0), ODK(2, 0), ODK(3, 0), ODK(4, 0), ODK(4, OSV_FAKE_CHAIN),
+                                                        ODK(1, OSV_NT_LOAD), ODK(2, OSV_NT_LOAD), ODK(3, OSV_NT_LOAD),
+                                                        ODK(4, OSV_NT_LOAD), ODK(1, OSV_STATS), ODK(2, OSV_STATS),
+                                                        ODK(3, OSV_STATS), ODK(4, OSV_STATS),
+                                                        ODK(1, OSV_STATS | OSV_NO_PREFETCH), ODK(2, OSV_STATS | OSV_NO_PREFETCH),
+                                                        ODK(3, OSV_STATS | OSV_NO_PREFETCH), ODK(4, OSV_STATS | OSV_NO_PREFETCH),
+                                                        // experiments: a wider window of the chained scan
+                                                        ODKL(1, 0, 16), ODKL(2, 0, 16), ODKL(3, 0, 16), ODKL(4, 0, 16),
+                                                        ODKL(1, OSV_STATS | OSV_NO_PREFETCH, 16), ODKL(2, OSV_STATS | OSV_NO_PREFETCH, 16),
+                                                        ODKL(3, OSV_STATS | OSV_NO_PREFETCH, 16), ODKL(4, OSV_STATS | OSV_NO_PREFETCH, 16)};
 #undef ODK
+#undef ODKL
                 const char *sv = getenv("MGS_OSD_FAKECHAIN"); // timing only: no chained scan, wrong output
-                const int ki = (sv && atoi(sv) && ov_k == 4) ? 4 : ov_k - 1;
+                const char *cv = getenv("MGS_OSD_CHECKED");   // debugging: stores outside the buffers are counted, not made
+                int ki = (sv && atoi(sv) && ov_k == 4) ? 4 : ov_k - 1;
+                if (const char *fv = getenv("MGS_OSD_DBG_FLAGS")) q.dbg_flags = (uint32_t) atoi(fv); // timing experiments
+                if (const char *tv = getenv("MGS_OSD_STATS")) // diagnostic: per-phase cycles in Ctrl::head.stats
+                    if (atoi(tv)) ki = (atoi(tv) == 2 ? 12 : 8) + ov_k; // 2: the scan wave's phases
+                if (const char *lv = getenv("MGS_OSD_LOOK")) // experiment: 16 loads per poll of the chained scan
+                    if (atoi(lv) == 16) ki = (ki >= 13 ? 20 : 16) + ov_k;
+                if (cv && atoi(cv)) {
+                    ki = 4 + ov_k;
+                    q.dbg_lo[0] = (uint64_t) (uintptr_t) d_send_image;
+                    q.dbg_hi[0] = q.dbg_lo[0] + (uint64_t) (max_rounds - 1) * (uint64_t) image_stride
+                                  + (uint64_t) P * (uint64_t) D.buf_size;
+                    q.dbg_lo[1] = (uint64_t) (uintptr_t) d_local_out;
+                    q.dbg_hi[1] = q.dbg_lo[1] + (uint64_t) (d_local_out ? local_cap : 0);
+                }
                 hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
                 if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
                 const size_t items = (size_t) max_rounds * ((size_t) P + 1);
@@ -792,7 +829,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                 h->pending_rounds = max_rounds;
             }
             h->pending_ov_k = ov_k;
-            h->last_algo = "onesweepv";
+            h->last_algo = legacy ? "onesweepv" : "onesweepd";
         }
         if (!osv || may_fall_back) {
         int rc = ensure_generic_scratch(h, d_dest_out == nullptr);
@@ -884,7 +921,7 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
             h->err = "records too long for the one-sweep kernel's LDS staging: pack this batch round by round";
             return MGS_ERR_RECORD_SIZE;
         }
-        if (h->ov_k > 1) h->ov_k--; // the next call tries a smaller tile
+        h->ov_shrink++; // the next call tries a smaller tile
         // the generic kernels redo the call (same stream, same arguments)
         int64_t init[MGS_MAX_RANKS];
         memcpy(init, h->pending_init, sizeof(init));
@@ -927,17 +964,12 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
     }
     for (int b = P; b < MGS_MAX_RANKS; b++) out->send_offset[b] = 0;
     if (h->fixed_len == 0) {
-        // Variable width: pick the next call's tile from this call's record length
-        // (a quarter of head-room: lengths vary from tile to tile); after a fall-back
-        // with nothing learnt, halve it.
+        // Variable width: the next call picks its tile from this call's record length
         const uint64_t recs = out->next - h->pending_start;
         int64_t bytes = out->local_bytes;
         for (int b = 0; b < P; b++) bytes += out->send_offset[b] - h->pending_init[b];
-        if (recs > 0 && bytes > 0) {
-            const int k = ov_pick_k(1.25 * (double) bytes / (double) recs);
-            h->ov_k = k ? k : 1;
-        }
-
+        if (recs > 0 && bytes > 0 && h->pending_rounds <= 1) h->ov_bytes_per_record = (double) bytes / (double) recs;
+        if (h->pending_osv) h->ov_shrink = 0; // a one-sweep kernel served the call: the length alone decides again
     }
     return MGS_OK;
 }
@@ -968,7 +1000,7 @@ static int rounds_in_kernel(const mgs_handle *h, const void *d_records, void *d_
     for (int b = 0; b < D.nranks && os16 && init_offset; b++) os16 = (init_offset[b] % 16) == 0;
     if (os16) return MGS_ALGO_ONESWEEP16;
     if (algo == MGS_ALGO_ONESWEEP16) return 0;
-    const bool osd = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEPV) && !osv_legacy()
+    const bool osd = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEPV) && !osv_image_kernel(h, 2)
                      && D.nranks + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
                      && (h->fixed_len == 0 || od_pick_k((double) h->fixed_len) != 0);
     return osd ? MGS_ALGO_ONESWEEPV : 0;

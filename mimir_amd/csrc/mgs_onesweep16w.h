@@ -35,6 +35,8 @@ struct OsWalkStats { // per scan wave, flushed to Ctrl::stats once at the end of
     unsigned long long max_depth = 0, max_cycles = 0, max_polls = 0;
     // windowed scan only: first polls that did not finish, by cause
     unsigned long long fail_near = 0, fail_far = 0, fail_base = 0;
+    // rounds: cycles spent waiting for a round's table entry / finding cuts, and how often
+    unsigned long long rt_wait_cycles = 0, rt_waits = 0, cut_cycles = 0;
     bool windowed = false;
     __device__ void flush(Ctrl *ctrl) const
     {
@@ -44,6 +46,12 @@ struct OsWalkStats { // per scan wave, flushed to Ctrl::stats once at the end of
             atomicAdd(&ctrl->head.stats[2], idle);
             atomicAdd(&ctrl->head.stats[3], depth);
             atomicAdd(&ctrl->head.stats[4], cycles);
+            if (rt_waits || cut_cycles) { // a call with round cuts reports those instead
+                atomicAdd(&ctrl->head.stats[5], rt_wait_cycles);
+                atomicAdd(&ctrl->head.stats[6], rt_waits);
+                atomicAdd(&ctrl->head.stats[7], cut_cycles);
+                return;
+            }
             atomicAdd(&ctrl->head.stats[5], fail_near);
             atomicAdd(&ctrl->head.stats[6], fail_far);
             atomicAdd(&ctrl->head.stats[7], fail_base);
@@ -337,10 +345,11 @@ struct OsCutLds {
 template <int NB, int SEG>
 __device__ __forceinline__ void os_find_cuts16(const OsParams &p, uint32_t tile, int nseg, int lane,
                                             unsigned long long acc, uint32_t tot, const uint32_t *wc,
-                                            bool is_part, unsigned long long my_cap, uint32_t &k_cur,
-                                            unsigned long long &base, unsigned long long &lim,
+                                            const unsigned long long *sde, bool is_part, unsigned long long my_cap,
+                                            uint32_t &k_cur, unsigned long long &base, unsigned long long &lim,
                                             unsigned long long &first_nb, OsCutLds *x)
 {
+    static_assert(SEG == 8, "a lane's destinations of one wave segment are one 8-byte word");
     const uint32_t P = p.P;
     const uint32_t k_in = k_cur;
     uint32_t c = 0, wst = (uint32_t) nseg;
@@ -360,80 +369,93 @@ __device__ __forceinline__ void os_find_cuts16(const OsParams &p, uint32_t tile,
     __builtin_amdgcn_wave_barrier();
     const uint64_t t0 = (uint64_t) tile * p.tile_records;
     bool stop = false;
-    // One wave segment (SEG rows of 64 records) at a time: all its records are requested
-    // at once, so that the walk waits for memory once per segment and not once per row
-    // (a round trip takes microseconds while the chip streams, and every later tile
-    // waits for the round this walk publishes).
     for (int seg = (int) wstar; seg < nseg && !stop; seg++) {
-    static_assert(SEG <= 8, "the destinations of a segment's rows are packed into two registers");
-    uint4 rr[SEG];
+        // the destinations of this lane's records in the segment's SEG rows (byte j = row j,
+        // 0xFF = no record), left in LDS by the worker wave that hashed them
+        const unsigned long long dq = sde[seg * 64 + lane];
+        const uint32_t dpack[2] = {(uint32_t) dq, (uint32_t) (dq >> 32)};
+        // Fast-forward: rows in which no partition overflows hold no cut; find the first row
+        // that does (per overflowing destination: rows counted with wave ballots) and add the
+        // rows before it to the running totals in one go.
+        const unsigned long long left = x->lim[lane] - x->pos[lane]; // lane = column: units that still fit
+        uint64_t cand = __ballot(is_part && acc + tot > lim);
+        int row0 = SEG;
+        while (cand) {
+            const int b = __ffsll((unsigned long long) cand) - 1;
+            cand &= cand - 1;
+            const unsigned long long room = (unsigned long long) __shfl((long long) left, b);
+            unsigned long long cum = 0;
+            int rb = SEG;
 #pragma unroll
-    for (int j = 0; j < SEG; j++) {
-        const uint64_t i = t0 + (uint32_t) (seg * SEG + j) * 64 + lane;
-        rr[j] = (i < p.n) ? p.rec[i] : make_uint4(0, 0, 0, 0);
-    }
-    uint32_t dpack[2] = {0, 0}; // destination of this lane's record in row j: byte j
-#pragma unroll
-    for (int j = 0; j < SEG; j++)
-        dpack[j >> 2] |= fastmod(hash_rec16(rr[j].x, rr[j].y, rr[j].z, rr[j].w, p.klen), p.fm) << (8 * (j & 3));
-#pragma unroll 1
-    for (int j = 0; j < SEG; j++) {
-        if (stop) break;
-        const int row = seg * SEG + j;
-        const uint64_t i = t0 + (uint32_t) row * 64 + lane;
-        const bool valid = i < p.n;
-        const uint32_t d = ((j < 4 ? dpack[0] : dpack[1]) >> (8 * (j & 3))) & 0xffu;
-        uint64_t m = __ballot(valid);
-#pragma unroll
-        for (uint32_t bit = 0; bit < (uint32_t) NB; bit++) {
-            const bool one = (d >> bit) & 1u;
-            const uint64_t bk = __ballot(one);
-            m &= one ? bk : ~bk;
+            for (int j = 0; j < SEG; j++) {
+                cum += (unsigned long long) __popcll(__ballot(((dpack[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t) b));
+                if (cum > room && rb == SEG) rb = j;
+            }
+            row0 = rb < row0 ? rb : row0;
         }
-        const uint32_t rank = lanes_below(m);
-        uint64_t open = ~0ull; // lanes not yet given to a finished round
-        for (;;) {
-            const bool over = valid && ((open >> lane) & 1ull) && x->pos[d] + rank >= x->lim[d];
-            const uint64_t om = __ballot(over);
-            if (!om) break;
-            const int fl = __ffsll((unsigned long long) om) - 1;
-            const uint64_t below = (1ull << fl) - 1ull;
-            x->cnt[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            if (valid && lane < fl && rank == 0) x->cnt[d] = (uint32_t) __popcll(m & below);
-            __builtin_amdgcn_wave_barrier();
-            // the round that begins with record (row, fl)
-            k_cur++;
-            const unsigned long long nb = x->pos[lane] + x->cnt[lane];
-            if (k_cur == k_in + 1) first_nb = nb;
-            if ((uint32_t) lane < P) os_store_status(p.rt + (uint64_t) k_cur * P + lane, OS_RT_VALID | nb);
-            if (lane == 0) {
-                os_store_status(p.rt_start + k_cur, OS_RT_VALID | (t0 + (uint32_t) row * 64 + (uint32_t) fl));
-                atomicMax(&p.ctrl->head.rounds_cut, k_cur);
-            }
-            if (is_part) {
-                base = nb;
-                lim = nb + my_cap;
-                x->lim[lane] = lim;
-            }
-            __builtin_amdgcn_wave_barrier();
-            open &= ~below;
-            if (k_cur >= p.max_rounds) {
-                stop = true; // the end marker: nothing from here on is consumed
-                break;
-            }
-            // a record that does not fit an empty partition (src/collectiveshuffler.h:156-159)
-            const bool never = valid && lane == fl && x->pos[d] + rank >= x->lim[d];
-            if (__ballot(never)) {
-                raise_error(p.ctrl, MGS_ERR_RECORD_SIZE);
-                stop = true;
-                break;
-            }
+#pragma unroll
+        for (int j = 0; j < SEG; j++) {
+            const uint32_t dj = (dpack[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            if (j < row0 && dj != 0xffu) atomicAdd(const_cast<unsigned long long *>(&x->pos[dj]), 1ull);
         }
-        if (valid && rank == 0) x->pos[d] += (unsigned long long) __popcll(m);
         __builtin_amdgcn_wave_barrier();
-        if (!__ballot(is_part && acc + tot > lim)) stop = true; // no cut in what is left of the tile
-    }
+#pragma unroll 1
+        for (int j = row0; j < SEG; j++) {
+            if (stop) break;
+            const int row = seg * SEG + j;
+            const uint32_t d = ((j < 4 ? dpack[0] : dpack[1]) >> (8 * (j & 3))) & 0xffu;
+            const bool valid = d != 0xffu;
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (uint32_t bit = 0; bit < (uint32_t) NB; bit++) {
+                const bool one = (d >> bit) & 1u;
+                const uint64_t bk = __ballot(one);
+                m &= one ? bk : ~bk;
+            }
+            const uint32_t rank = lanes_below(m);
+            uint64_t open = ~0ull; // lanes not yet given to a finished round
+            for (;;) {
+                const bool over = valid && ((open >> lane) & 1ull) && x->pos[d] + rank >= x->lim[d];
+                const uint64_t om = __ballot(over);
+                if (!om) break;
+                const int fl = __ffsll((unsigned long long) om) - 1;
+                const uint64_t below = (1ull << fl) - 1ull;
+                x->cnt[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (valid && lane < fl && rank == 0) x->cnt[d] = (uint32_t) __popcll(m & below);
+                __builtin_amdgcn_wave_barrier();
+                // the round that begins with record (row, fl)
+                k_cur++;
+                const unsigned long long nb = x->pos[lane] + x->cnt[lane];
+                if (k_cur == k_in + 1) first_nb = nb;
+                if ((uint32_t) lane < P) os_store_status(p.rt + (uint64_t) k_cur * P + lane, OS_RT_VALID | nb);
+                if (lane == 0) {
+                    os_store_status(p.rt_start + k_cur, OS_RT_VALID | (t0 + (uint32_t) row * 64 + (uint32_t) fl));
+                    atomicMax(&p.ctrl->head.rounds_cut, k_cur);
+                }
+                if (is_part) {
+                    base = nb;
+                    lim = nb + my_cap;
+                    x->lim[lane] = lim;
+                }
+                __builtin_amdgcn_wave_barrier();
+                open &= ~below;
+                // a record that does not fit an empty partition (src/collectiveshuffler.h:156-159)
+                const bool never = valid && lane == fl && x->pos[d] + rank >= x->lim[d];
+                if (__ballot(never)) {
+                    raise_error(p.ctrl, MGS_ERR_RECORD_SIZE);
+                    stop = true;
+                    break;
+                }
+                if (k_cur >= p.max_rounds) {
+                    stop = true; // the end marker: nothing from here on is consumed
+                    break;
+                }
+            }
+            if (valid && rank == 0) x->pos[d] += (unsigned long long) __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (!__ballot(is_part && acc + tot > lim)) stop = true; // no cut in what is left of the tile
+        }
     }
 }
 
@@ -467,6 +489,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
                                           // [4+par] / [6+par] first / last round of the tile
     __shared__ uint32_t arrive[2];        // worker waves done hashing, per tile parity
     __shared__ OsCutLds cutlds;           // scan wave only, tiles that hold a round cut
+    // destination of every record in emit order, two tiles: entry (wave, lane) holds the lane's
+    // ITEMS records, byte k = row k (0xFF: no record); read only for tiles that hold a round cut
+    __shared__ unsigned long long sde[2 * WTHREADS];
     __shared__ unsigned long long rb2[2 * 2 * OS_MAXP]; // per parity: totals at the first record of the tile's
                                                         // first round and of the round after it (checked path)
 
@@ -534,7 +559,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
             if (!(VAR & OSV_FAKE_CHAIN) && k_cur < p.max_rounds) {
                 while (__ballot(is_part && acc > lim)) {
                     k_cur++;
+                    unsigned long long st0 = 0;
+                    if (VAR & OSV_STATS) st0 = __builtin_readcyclecounter();
                     const unsigned long long nb = os_rt_wait(p, k_cur, lane, (uint32_t) lane < P);
+                    if (VAR & OSV_STATS) {
+                        ws.rt_wait_cycles += __builtin_readcyclecounter() - st0;
+                        ws.rt_waits++;
+                    }
                     if (is_part) {
                         base = nb;
                         lim = nb + my_cap;
@@ -554,8 +585,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
             else if (__ballot(is_part && acc + tot > lim)) {
                 unsigned long long first_nb = 0;
                 rb2[(par * 2 + 0) * OS_MAXP + lane] = base;
-                os_find_cuts16<NB, ITEMS>(p, tile, WORKERS, lane, acc, tot, wc, is_part, my_cap, k_cur, base, lim,
-                                          first_nb, &cutlds);
+                unsigned long long st0 = 0;
+                if (VAR & OSV_STATS) st0 = __builtin_readcyclecounter();
+                os_find_cuts16<NB, ITEMS>(p, tile, WORKERS, lane, acc, tot, wc, sde + par * WTHREADS, is_part, my_cap,
+                                          k_cur, base, lim, first_nb, &cutlds);
+                if (VAR & OSV_STATS) ws.cut_cycles += __builtin_readcyclecounter() - st0;
                 rb2[(par * 2 + 1) * OS_MAXP + lane] = first_nb;
                 mode = 0;
             }
@@ -662,6 +696,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
 #pragma unroll
             for (int k = 0; k < ITEMS; k++)
                 if ((meta[k] >> 31) != 0) p.dest_out[idx0 + (uint32_t) k * 64] = (uint8_t) (meta[k] & 0xffu);
+        }
+        {
+            static_assert(ITEMS == 8, "a lane's destinations are packed into one 8-byte word");
+            uint32_t dlo = 0, dhi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                dlo |= ((meta[k] >> 31) ? (meta[k] & 0xffu) : 0xffu) << (8 * k);
+                dhi |= ((meta[k + 4] >> 31) ? (meta[k + 4] & 0xffu) : 0xffu) << (8 * k);
+            }
+            sde[par * WTHREADS + tid] = ((unsigned long long) dhi << 32) | dlo;
         }
         if (VAR & OSV_EARLY_AGG) {
             // The last worker wave to finish hashing publishes the tile's counts, before

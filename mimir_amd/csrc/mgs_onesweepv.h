@@ -63,6 +63,10 @@ struct OvParams {
     // os.lpt_log follow os.P.  Also self, fm, ntiles, tile_records, status, agg16,
     // dest_out, ctrl.
     OsParams os;
+    // checked build of k_onesweepd (debugging aid): every store must lie inside one of two
+    // address ranges (send images, local stream); a store that does not is counted, not made
+    uint64_t dbg_lo[2], dbg_hi[2];
+    uint32_t dbg_flags; // timing experiments (wrong output): 1 = no fast-path stores, 2 = only the first store of a record
 };
 
 struct __attribute__((packed)) OvU16 { uint16_t v; };
@@ -306,9 +310,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
     struct Offsets {
         uint64_t base;
         uint32_t rec[K + 1], s, e;
+        uint32_t nrec; // records of the tile
     };
     auto fetch_offsets = [&](uint32_t t, Offsets &f) {
         const uint64_t i0 = (uint64_t) t * T, i1 = min(q.n, i0 + T);
+        f.nrec = (uint32_t) (i1 - i0);
         if (q.rec_off) {
             const uint32_t *ro = q.rec_off + q.first;
             f.base = 0;
@@ -354,7 +360,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
             const uint32_t r = f.rec[k] - f.s;
             lo[k] = r + shift;
             len[k] = l;
-            if (l == 0) continue; // past the end of the call
+            if (l == 0) { // past the end of the call -- or an empty record, which no layout produces
+                if ((uint32_t) (wt * K + k) < f.nrec) raise_error(p.ctrl, MGS_ERR_MALFORMED);
+                continue;
+            }
             if (l > GEN_MAX_RECORD || f.rec[k] < f.s || (uint64_t) r + shift + l > span) {
                 raise_error(p.ctrl, MGS_ERR_MALFORMED);
                 len[k] = 0;
@@ -434,6 +443,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
     Offsets fn;
     fn.base = 0;
     fn.s = fn.e = 0;
+    fn.nrec = 0;
     {
         // first tile: offsets, then bytes, then park them
         Offsets f0;
@@ -488,10 +498,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
                 const uint32_t m0 = klen >= 4 ? 0xFFFFFFFFu : ((1u << (8 * klen)) - 1u);
                 const uint32_t m1 = klen >= 8 ? 0xFFFFFFFFu : (klen > 4 ? ((1u << (8 * (klen - 4))) - 1u) : 0u);
                 const uint32_t m2 = klen >= 12 ? 0xFFFFFFFFu : (klen > 8 ? ((1u << (8 * (klen - 8))) - 1u) : 0u);
-                if (LM == 1) { // the key's last byte must be its NUL
-                    const uint32_t last = klen - 1;
-                    const uint32_t wl = last >= 8 ? w2 : (last >= 4 ? w1 : w0);
-                    ok = ((wl >> (8 * (last & 3u))) & 0xFFu) == 0;
+                if (LM == 1) {
+                    // the key's first NUL must be its last byte (strlen + 1, src/serializer.h:131-136):
+                    // zero-byte flags of the three words with the bytes beyond the key set to 0xFF
+                    const uint32_t t0 = w0 | ~m0, t1 = w1 | ~m1, t2 = w2 | ~m2;
+                    const uint32_t z0 = (t0 - 0x01010101u) & ~t0 & 0x80808080u, z1 = (t1 - 0x01010101u) & ~t1 & 0x80808080u,
+                                   z2 = (t2 - 0x01010101u) & ~t2 & 0x80808080u;
+                    const uint32_t fz = z0 ? ((uint32_t) __builtin_ctz(z0) >> 3)
+                                           : (z1 ? 4u + ((uint32_t) __builtin_ctz(z1) >> 3)
+                                                 : (z2 ? 8u + ((uint32_t) __builtin_ctz(z2) >> 3) : 99u));
+                    ok = fz == klen - 1;
                 }
                 uint32_t a, b, c;
                 a = b = c = 0xdeadbeefu + klen;
@@ -502,7 +518,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
                 h[k] = c;
             }
             else if (ok) {
-                if (LM == 1) ok = r[klen - 1] == 0;
+                if (LM == 1) {
+                    ok = r[klen - 1] == 0;
+                    for (uint32_t j = 0; j + 1 < klen; j++) ok = ok && r[j] != 0;
+                }
                 h[k] = ov_hash_lds(sin, lo[k], klen);
             }
             if (!ok) {
@@ -603,6 +622,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
         Offsets fn2;
         fn2.base = 0;
         fn2.s = fn2.e = 0;
+        fn2.nrec = 0;
         if (next2 < p.ntiles) fetch_offsets(next2, fn2);
         {
             // reorder: all reads first (the first 16 bytes of every record, and where it

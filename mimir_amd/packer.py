@@ -58,7 +58,7 @@ class DevicePacker:
     """
 
     def __init__(self, layout, nranks, rank, buf_size, max_records,
-                 device=0):
+                 device=0, flags=0):
         self.lib = capi.load()
         self.layout = layout
         self.nranks = nranks
@@ -66,7 +66,7 @@ class DevicePacker:
         self.buf_size = int(buf_size)
         self.device = int(device)
         self.max_records = int(max_records)
-        desc = capi.Desc(nranks, rank, layout, self.buf_size, self.device, 0,
+        desc = capi.Desc(nranks, rank, layout, self.buf_size, self.device, int(flags),
                          self.max_records)
         h = C.c_void_p()
         rc = self.lib.mgs_create(C.byref(desc), C.byref(h))

@@ -542,7 +542,10 @@ class NBGpuShuffler(GpuShuffler):
                     self.recv_bytes += int(m.recv_count.sum())
                     m.state = _MsgBuf.PENDING
                     self.a2av_token += 1
-            if m.state == _MsgBuf.PENDING:
+            if m.state == _MsgBuf.PENDING and not any(
+                    o.state == _MsgBuf.PENDING and o.token < m.token for o in self.msg):
+                # Rounds reach `out` in the order they were sent (the reference hands completed
+                # exchanges over in buffer-index order, :362-383, which can swap two rounds).
                 # gloo's point-to-point requests only complete inside wait(): block there.
                 # Payloads are posted in token order on every rank, so this cannot deadlock;
                 # it only gives up the overlap, which matters on RCCL, where polling works.

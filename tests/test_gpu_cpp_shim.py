@@ -86,7 +86,14 @@ def test_cpp_nonblocking_shim_matches_reference(oracle, kind, P, keycount):
             for i in range(len(src)):
                 by_src[int(src[i])].append(data[int(off[i]):int(off[i + 1])])
             for s in range(P):
-                assert by_src[s] == per[r][s], f"rank {r}: records from {s} differ"
+                if by_src[s] != per[r][s]:
+                    got_s, want_s = by_src[s], per[r][s]
+                    first = next((i for i in range(min(len(got_s), len(want_s))) if got_s[i] != want_s[i]),
+                                 min(len(got_s), len(want_s)))
+                    raise AssertionError(
+                        f"rank {r}: records from {s} differ: {len(got_s)} received, {len(want_s)} expected, first "
+                        f"difference at record {first}: {got_s[first:first + 2]} vs {want_s[first:first + 2]}; "
+                        f"same multiset: {sorted(got_s) == sorted(want_s)}")
             kv, times, buffers = open(os.path.join(outd, f"rank{r}.txt")).read().split()
             assert int(kv) == kvcount[r]
             assert 2 <= int(buffers) <= 5

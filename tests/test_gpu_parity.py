@@ -23,7 +23,19 @@ def _layouts(t):
 
 def run_and_compare(oracle, blob, offs, lay_t, n, P, rank, buf_size, algo,
                     start=0, init=None, max_records=None, check_dest=True):
-    """One pack call on the GPU vs one oracle round.  Returns the GPU result."""
+    """One pack call on the GPU vs one oracle round.  Returns the GPU result.
+    Layouts the byte-granular one-sweep kernels take are run through both of them: the
+    LDS-image kernel (the default for a one-round call) and the round-cutting kernel."""
+    first = _run_and_compare(oracle, blob, offs, lay_t, n, P, rank, buf_size, algo, start, init, max_records,
+                             check_dest, 0)
+    if first[1] == "onesweepv":
+        _, name = _run_and_compare(oracle, blob, offs, lay_t, n, P, rank, buf_size, algo, start, init, max_records,
+                                   check_dest, capi.FLAG_OSV_ROUNDS_KERNEL)
+        assert name in ("onesweepd", "generic"), name
+    return first
+
+
+def _run_and_compare(oracle, blob, offs, lay_t, n, P, rank, buf_size, algo, start, init, max_records, check_dest, flags):
     torch = _torch()
     from mimir_amd.packer import DevicePacker
     glay, olay = _layouts(lay_t)
@@ -36,7 +48,7 @@ def run_and_compare(oracle, blob, offs, lay_t, n, P, rank, buf_size, algo,
     if offs is not None:
         assert int(offs[-1]) < (1 << 32)
         d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).to(dev)
-    pk = DevicePacker(glay, P, rank, buf_size, max_records or max(n, 1))
+    pk = DevicePacker(glay, P, rank, buf_size, max_records or max(n, 1), flags=flags)
     image = torch.full((P * buf_size,), 0xEE, dtype=torch.uint8, device=dev)
     local = torch.full((max(len(blob), 16),), 0xDD, dtype=torch.uint8, device=dev) if rank >= 0 else None
     dest = torch.full((max(n - start, 1),), 0xFF, dtype=torch.uint8, device=dev)
@@ -365,7 +377,7 @@ def test_onesweepv_adapts_tile_to_record_length(oracle):
     torch = _torch()
     from mimir_amd.packer import DevicePacker
     n = 30000
-    blob, offs, lay = datagen.join_records(n, n_unique=2000, alpha=1.0, len_mean=14, len_sd=3, seed=46)
+    blob, offs, lay = datagen.join_records(n, n_unique=2000, alpha=1.0, len_mean=30, len_sd=3, seed=46)
     glay, olay = _layouts(lay)
     total = int(offs[-1])
     want = oracle.pack_round(olay, blob, offs, n, 0, 8, 2, total)
@@ -581,14 +593,15 @@ def test_malformed_records_are_refused_like_the_oracle(oracle, algo, bad):
         n = len(recs)
         with pytest.raises(ValueError):
             oracle.pack_round(olay, blob, offs, n, 0, 4, 1, 1 << 20)
-        pk = DevicePacker(glay, 4, 1, 1 << 20, n)
-        image = torch.empty(4 << 20, dtype=torch.uint8, device="cuda:0")
-        local = torch.empty(1 << 20, dtype=torch.uint8, device="cuda:0")
-        d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
-        with pytest.raises(capi.MgsError) as ei:
-            pk.pack(torch.from_numpy(blob).cuda(), n, image, rec_off=d_off, local_out=local, algo=algo)
-        assert ei.value.status == capi.ERR_MALFORMED, (bad, where, pk.last_algo())
-        pk.close()
+        for flags in (0, capi.FLAG_OSV_ROUNDS_KERNEL):
+            pk = DevicePacker(glay, 4, 1, 1 << 20, n, flags=flags)
+            image = torch.empty(4 << 20, dtype=torch.uint8, device="cuda:0")
+            local = torch.empty(1 << 20, dtype=torch.uint8, device="cuda:0")
+            d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+            with pytest.raises(capi.MgsError) as ei:
+                pk.pack(torch.from_numpy(blob).cuda(), n, image, rec_off=d_off, local_out=local, algo=algo)
+            assert ei.value.status == capi.ERR_MALFORMED, (bad, where, pk.last_algo())
+            pk.close()
 
 
 def test_two_string_keys_with_fixed_value(oracle):
