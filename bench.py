@@ -182,6 +182,11 @@ def main():
                          "partitions get the reference's geometry and the batch is cut into rounds as "
                          "CollectiveShuffler::write cuts it.  0: one round sized to hold the whole batch. "
                          "Default: 64M.")
+    ap.add_argument("--layout", default="streams", choices=["streams", "images"],
+                    help="how the rounds of a batch lie in memory.  streams: one stream per destination, the "
+                         "rounds are views into it (mgs_pack_streams_device: the sweep never waits for a round "
+                         "cut); images: one send image per round (mgs_pack_rounds_device).  Same rounds, same "
+                         "bytes per partition either way.")
     args = ap.parse_args()
     if args.workload != "u64" and args.records == 1e9:
         args.records = 5e7
@@ -257,8 +262,15 @@ def main():
         max_rounds = 1
         rounds_note = "one round holds the batch"
     stride = P * buf_size
+    streams_layout = bool(comm_size) and args.layout == "streams"
     pk = DevicePacker(lay, P, self_rank, buf_size, max_records=n, device=dev)
-    images = torch.empty(max_rounds * stride, dtype=torch.uint8, device=f"cuda:{dev}")
+    if streams_layout:
+        # one stream per destination, sized for its share of the batch plus slack
+        stream_cap = (int(total_bytes * hot_share) + total_bytes // 64 + 65536) // 16 * 16
+        images = torch.empty(P * stream_cap, dtype=torch.uint8, device=f"cuda:{dev}")
+        rounds_note += "; rounds are views into one stream per destination"
+    else:
+        images = torch.empty(max_rounds * stride, dtype=torch.uint8, device=f"cuda:{dev}")
     local = recv = None
     if distributed:
         local = torch.empty(int(total_bytes * hot_share) + total_bytes // 64 + 65536, dtype=torch.uint8,
@@ -270,7 +282,10 @@ def main():
 
     def step():
         t0 = time.perf_counter()
-        r = pk.pack_rounds(records, n, images, stride, max_rounds, rec_off=rec_off, local_out=local, algo=algo)
+        if streams_layout:
+            r = pk.pack_streams(records, n, images, stream_cap, max_rounds, rec_off=rec_off, local_out=local)
+        else:
+            r = pk.pack_rounds(records, n, images, stride, max_rounds, rec_off=rec_off, local_out=local, algo=algo)
         pack_s.append(time.perf_counter() - t0)
         if r.next != n:
             raise RuntimeError(f"{r.n_rounds} rounds used up at record {r.next} of {n}: raise max_rounds")
@@ -278,12 +293,13 @@ def main():
         stats["rounds"] = r.n_rounds
         if distributed:
             so = r.round_send_offset
+            part, bases = (stream_cap, r.round_base) if streams_layout else (buf_size, None)
             if backend == "gloo":   # rehearsal: through host memory
                 host_recv = torch.empty(recv.shape, dtype=torch.uint8)
-                rc, R = exchange_rounds(images.cpu(), stride, so, buf_size, host_recv, stride)
+                rc, R = exchange_rounds(images.cpu(), stride, so, part, host_recv, stride, round_base=bases)
                 recv.copy_(host_recv)
             else:
-                rc, R = exchange_rounds(images, stride, so, buf_size, recv, stride)
+                rc, R = exchange_rounds(images, stride, so, part, recv, stride, round_base=bases)
             stats["exchanges"] = R
             stats["sent_max"] = max(stats["sent_max"], int(so.sum(axis=0).max()))
         return r
@@ -311,7 +327,8 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = n * world * args.steps / dt
-    in_kernel = pk.last_algo() in ("onesweep16", "onesweepd") or max_rounds == 1 or stats["rounds"] == 1
+    in_kernel = (pk.last_algo() in ("onesweep16", "onesweepd") or max_rounds == 1 or stats["rounds"] == 1
+                 or streams_layout)
     # one kernel covers the step (16-byte records cut their rounds inside the kernel); the
     # other layouts run one kernel sequence per round: price the pack calls' wall time then
     k_ms = sum(kernel_ms) / len(kernel_ms) if in_kernel else sum(pack_s) / len(pack_s) * 1e3
@@ -344,6 +361,7 @@ def main():
             "records_per_gpu": n, "record_bytes": total_bytes / n, "partitions": P,
             "local_bypass": distributed, "kernel_variant": kname,
             "partition_bytes": buf_size, "rounds": stats["rounds"], "rounds_note": rounds_note,
+            "layout": "streams" if streams_layout else ("images" if comm_size else "one round"),
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,

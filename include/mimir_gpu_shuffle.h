@@ -262,6 +262,61 @@ int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next,
                            uint64_t *round_local_records,
                            int64_t *round_local_bytes);
 
+/* Many rounds per call, streams layout.  The same rounds as mgs_pack_rounds_device
+ * (src/collectiveshuffler.h:131-166: a round ends before the first record that
+ * does not fit its partition of buf_size bytes), but the partitions of a round
+ * are not copied to an image of their own: the call appends the records of
+ * [start, n_end) to nranks destination streams -- stream b at d_streams +
+ * b * stream_cap, stream_cap bytes long, stream_fill[b] bytes already there
+ * (NULL = empty) -- and reports every round as a view into the streams:
+ *
+ *   round_base[k*nranks + b]         byte of stream b at which partition b of
+ *                                    round k begins
+ *   round_send_offset[k*nranks + b]  its length: the send_offset of the k-th
+ *                                    exchange (src/collectiveshuffler.h:162)
+ *
+ * Bytes [round_base, round_base + round_send_offset) of stream b are byte for
+ * byte what the reference's send buffer holds at b*buf_size in that exchange;
+ * an all-to-all-v takes them with displacement b*stream_cap + round_base in
+ * place of b*buf_size (src/collectiveshuffler.h:630-645).  The other per-round
+ * arrays, out->n_rounds and out->next mean what they mean for
+ * mgs_pack_rounds_device.  open_round_base[b] (NULL = stream_fill) is the byte
+ * of stream b at which the round that is still open began: pass the last
+ * round's round_base of the previous call to go on in the same streams.
+ * out->next < n_end also when a stream is full: the last reported round is then
+ * open and ends with record out->next - 1.
+ *
+ * The sweep over the records knows nothing of rounds, so no tile ever waits
+ * for a round cut: one workgroup of the same launch trails the chained scan's
+ * prefixes and finds the cuts (mimir_amd/csrc/mgs_round_finder.h).  Layouts:
+ * what the one-sweep kernels take (at most 64 ranks, 63 with a local rank
+ * unless records are 16 bytes; fixed widths up to 79 bytes or variable width;
+ * 16-byte records need 16-byte aligned buffers, fills and stream_cap);
+ * MGS_ERR_ARG otherwise, MGS_ERR_RECORD_SIZE for variable-width records too
+ * long for the kernel's LDS staging (use mgs_pack_rounds_device there). */
+int mgs_pack_streams_device(mgs_handle *h, const void *d_records,
+                            const uint32_t *d_rec_off, uint64_t n_end,
+                            uint64_t start, const int64_t *stream_fill,
+                            const int64_t *open_round_base, void *d_streams,
+                            int64_t stream_cap, uint32_t max_rounds,
+                            void *d_local_out, int64_t local_cap,
+                            uint8_t *d_dest_out, void *stream, mgs_rounds *out,
+                            uint64_t *round_next, int64_t *round_send_offset,
+                            int64_t *round_base, uint64_t *round_local_records,
+                            int64_t *round_local_bytes);
+int mgs_pack_streams_device_async(mgs_handle *h, const void *d_records,
+                                  const uint32_t *d_rec_off, uint64_t n_end,
+                                  uint64_t start, const int64_t *stream_fill,
+                                  const int64_t *open_round_base,
+                                  void *d_streams, int64_t stream_cap,
+                                  uint32_t max_rounds, void *d_local_out,
+                                  int64_t local_cap, uint8_t *d_dest_out,
+                                  void *stream);
+int mgs_pack_streams_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next,
+                            int64_t *round_send_offset, int64_t *round_base,
+                            uint64_t *round_local_records,
+                            int64_t *round_local_bytes);
+
 /* mgs_pack_device for callers that cannot allocate: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
  * counterpart in the reference.  Same arguments, same kernels and same result
@@ -493,7 +548,11 @@ int mgs_last_kernel_ms(mgs_handle *h, float *ms);
  * reports the device time: what a perfect partitioner could reach here. */
 int mgs_set_tuning(mgs_handle *h, int variant);
 int mgs_get_tuning(const mgs_handle *h);
-int mgs_debug_stats(mgs_handle *h, uint64_t out[8]); /* counters of a "-stats" variant */
+int mgs_debug_stats(mgs_handle *h, uint64_t out[8]);
+/* Diagnostic: the round finder of the last completed streams-layout call: [0]
+ * its wall time in 100 MHz ticks, [1..3] shader cycles spent searching for the
+ * tiles that hold cuts, hashing those tiles, walking them. */
+int mgs_finder_stats(mgs_handle *h, uint64_t out[4]); /* counters of a "-stats" variant */
 const char *mgs_tuning_name(int variant);
 int mgs_copy_calibration(mgs_handle *h, const void *d_in, void *d_out,
                          uint64_t n_records, void *stream, float *ms);

@@ -93,6 +93,12 @@ SYMBOLS = {
     "mgs_pack_rounds_device_async": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP, _VP, C.c_int64,
                                                C.c_uint32, _VP, C.c_int64, _VP, C.c_int, _VP]),
     "mgs_pack_rounds_result": (C.c_int, [_VP, C.POINTER(Rounds), _VP, _VP, _VP, _VP]),
+    "mgs_pack_streams_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP, _VP, _VP, C.c_int64,
+                                          C.c_uint32, _VP, C.c_int64, _VP, _VP,
+                                          C.POINTER(Rounds), _VP, _VP, _VP, _VP, _VP]),
+    "mgs_pack_streams_device_async": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP, _VP, _VP, C.c_int64,
+                                                C.c_uint32, _VP, C.c_int64, _VP, _VP]),
+    "mgs_pack_streams_result": (C.c_int, [_VP, C.POINTER(Rounds), _VP, _VP, _VP, _VP, _VP]),
     "mgs_pack_device_noalloc": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP,
                                           _VP, _VP, C.c_int64, _VP, _VP,
                                           C.POINTER(Round)]),
@@ -101,6 +107,7 @@ SYMBOLS = {
     "mgs_get_tuning": (C.c_int, [_VP]),
     "mgs_tuning_name": (C.c_char_p, [C.c_int]),
     "mgs_debug_stats": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    "mgs_finder_stats": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "mgs_copy_calibration": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP,
                                        C.POINTER(C.c_float)]),
     "mgs_get_desc": (C.c_int, [_VP, C.POINTER(Desc)]),

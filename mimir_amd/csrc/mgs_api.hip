@@ -150,6 +150,7 @@ struct mgs_handle {
     unsigned long long *d_rt = nullptr, *d_rtab = nullptr, *h_rtab = nullptr;
     size_t rt_words = 0, rtab_words = 0;
     uint32_t pending_rounds = 0; // > 0: the call in flight leaves a result table for that many rounds
+    bool pending_streams = false; // ... in the streams layout (rounds are views into destination streams)
     uint8_t *d_unp = nullptr;   // receive-side scratch (chunk and piece tables, cuts, result)
     size_t unp_bytes = 0;
     uint8_t *d_grp = nullptr;   // reduce-side scratch (tables, sort buffers)
@@ -176,6 +177,7 @@ struct mgs_handle {
     hipStream_t pending_stream = nullptr;
     uint64_t pending_start = 0;
     int64_t pending_init[MGS_MAX_RANKS];
+    int64_t pending_base[MGS_MAX_RANKS]; // streams layout: where the open round began in each stream
     bool pending_empty = false;
     const char *last_algo = "none";
     std::string err;
@@ -192,10 +194,19 @@ struct mgs_handle {
     } while (0)
 
 // Round table ((R+1) entries of `columns` words + R+1 start words) and result table.
-static int ensure_round_tables(mgs_handle *h, uint32_t max_rounds, int columns, int P)
+// Streams layout: behind the finder's round table, the sweep's own two-entry table and
+// the clip words (1 + columns); the result table also holds the rounds' stream offsets.
+static size_t round_table_words(uint32_t max_rounds, int columns, bool streams)
 {
-    const size_t rtw = ((size_t) max_rounds + 1) * ((size_t) columns + 1);
-    const size_t tabw = os_rtab_words(max_rounds, (uint32_t) P);
+    size_t w = ((size_t) max_rounds + 1) * ((size_t) columns + 1);
+    if (streams) w += 2 * ((size_t) columns + 1) + 1 + (size_t) columns;
+    return w;
+}
+
+static int ensure_round_tables(mgs_handle *h, uint32_t max_rounds, int columns, int P, bool streams = false)
+{
+    const size_t rtw = round_table_words(max_rounds, columns, streams);
+    const size_t tabw = streams ? os_stab_words(max_rounds, (uint32_t) P) : os_rtab_words(max_rounds, (uint32_t) P);
     if (h->rt_words < rtw) {
         if (h->d_rt) MGS_HIP(h, hipFree(h->d_rt));
         h->d_rt = nullptr;
@@ -469,15 +480,24 @@ static int ov_pick_k(bool image_kernel, double bytes_per_record)
 // Enqueue one pack call.  noalloc: the control block and the chained-scan arrays live
 // in the device's static scratch array, nothing is allocated, only the one-sweep
 // kernels are available.
+// Streams layout: d_send_image is the first of nranks destination streams of `cap` bytes each;
+// init_offset = bytes already in each stream; round_base = byte of each stream at which the open
+// round began (NULL: at init_offset, the open round is empty).
+struct StreamsArgs {
+    int64_t cap;
+    const int64_t *round_base;
+};
+
 static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
                         uint64_t n_end, uint64_t start, const int64_t *init_offset,
                         void *d_send_image, void *d_local_out, int64_t local_cap,
                         uint8_t *d_dest_out, int algo, void *stream_v, bool noalloc,
-                        uint32_t max_rounds = 1, int64_t image_stride = 0)
+                        uint32_t max_rounds = 1, int64_t image_stride = 0, const StreamsArgs *sa = nullptr)
 {
     if (!h) return MGS_ERR_ARG;
     const mgs_desc &D = h->desc;
     const int P = D.nranks;
+    const int64_t part_cap = sa ? sa->cap : D.buf_size; // what the sweep may fill of each partition
     if (start > n_end) {
         h->err = "mgs_pack_device: start > n_end";
         return MGS_ERR_ARG;
@@ -496,8 +516,14 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     }
     for (int b = 0; b < P; b++) {
         const int64_t v = init_offset ? init_offset[b] : 0;
-        if (v < 0 || v > D.buf_size) {
-            h->err = fmt("mgs_pack_device: init_offset[%d]=%lld outside [0,buf_size]", b, (long long) v);
+        if (v < 0 || v > part_cap) {
+            h->err = fmt("mgs_pack_device: init_offset[%d]=%lld outside [0,%lld]", b, (long long) v, (long long) part_cap);
+            return MGS_ERR_ARG;
+        }
+        if (sa && sa->round_base && b != D.rank
+            && (sa->round_base[b] < 0 || sa->round_base[b] > v || v - sa->round_base[b] > D.buf_size)) {
+            h->err = fmt("mgs_pack_streams_device: open_round_base[%d]=%lld must lie in [fill - buf_size, fill] (fill %lld)",
+                         b, (long long) sa->round_base[b], (long long) v);
             return MGS_ERR_ARG;
         }
     }
@@ -543,6 +569,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     h->pending_stream = stream;
     h->pending_empty = (n == 0);
     h->pending_rounds = 0;
+    h->pending_streams = false;
     h->ev_valid = false;
     if (n == 0) {
         h->pending = true;
@@ -553,13 +580,14 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     // ---- choose the kernels -------------------------------------------------
     const uint8_t *rec0 = static_cast<const uint8_t *>(d_records);
     bool os_ok = h->fixed_len == 16 && P <= OS_MAXP && D.layout.key_kind == MGS_KEY_FIXED
-                 && D.layout.key_bytes <= 16 && (D.buf_size % 16) == 0
+                 && D.layout.key_bytes <= 16 && (D.buf_size % 16) == 0 && (part_cap % 16) == 0
                  && ((uintptr_t) rec0 % 16) == 0 && ((uintptr_t) d_send_image % 16) == 0
                  && (D.rank < 0 || ((uintptr_t) d_local_out % 16) == 0);
-    for (int b = 0; b < P && os_ok; b++) os_ok = (h->pending_init[b] % 16) == 0;
+    for (int b = 0; b < P && os_ok; b++)
+        os_ok = (h->pending_init[b] % 16) == 0 && (!sa || !sa->round_base || b == D.rank || (sa->round_base[b] % 16) == 0);
     // byte-granular one-sweep: chain columns = P (+1 for the local record count) <= 64, and for
     // fixed widths a tile that fits the LDS staging buffer (variable widths are checked on the device)
-    const bool image_kernel = osv_image_kernel(h, max_rounds) && !noalloc;
+    const bool image_kernel = (sa != nullptr || osv_image_kernel(h, max_rounds)) && !noalloc;
     const bool ov_ok = P + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
                        && (h->fixed_len == 0 || ov_pick_k(image_kernel, (double) h->fixed_len) != 0);
     // variable width: K follows the record length seen in earlier calls (mgs_pack_result);
@@ -580,6 +608,11 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     if (image_kernel && ov_k == 3) ov_k = 2;
     if (algo == MGS_ALGO_AUTO)
         algo = os_ok ? MGS_ALGO_ONESWEEP16 : (ov_ok ? MGS_ALGO_ONESWEEPV : MGS_ALGO_GENERIC);
+    if (sa && algo == MGS_ALGO_GENERIC) {
+        h->err = "mgs_pack_streams_device: this layout / rank count / alignment needs the generic kernels, which "
+                 "pack one round per call";
+        return MGS_ERR_ARG;
+    }
     if (noalloc && algo == MGS_ALGO_GENERIC) {
         h->err = "mgs_pack_device_noalloc: this layout / rank count needs the generic kernels, whose buffers "
                  "are allocated per handle (at most 64 ranks, fixed widths up to 79 bytes or variable width)";
@@ -617,9 +650,10 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             H->part_init[b] = 0;
         }
         else {
-            H->part_base[b] = (uint64_t)(uintptr_t) d_send_image + (uint64_t) b * (uint64_t) D.buf_size;
-            H->part_cap[b] = D.buf_size;
+            H->part_base[b] = (uint64_t)(uintptr_t) d_send_image + (uint64_t) b * (uint64_t) part_cap;
+            H->part_cap[b] = part_cap;
             H->part_init[b] = h->pending_init[b];
+            H->round_base0[b] = (sa && sa->round_base) ? sa->round_base[b] : h->pending_init[b];
         }
     }
     MGS_HIP(h, hipMemcpyAsync(d_ctrl, H, sizeof(CtrlHead), hipMemcpyHostToDevice, stream));
@@ -651,12 +685,44 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         p.unit_shift = 4;
         p.dest_out = d_dest_out;
         p.ctrl = d_ctrl;
+        p.rt = p.rt_start = nullptr;
+        p.max_rounds = 1;
+        p.image_stride = 0;
+        p.finder = 0;
+        p.f_max_rounds = 0;
+        p.f_cap = 0;
+        p.f_rt = p.f_rt_start = p.clip_out = nullptr;
         MGS_HIP(h, hipMemsetAsync(d_status, 0, (size_t) p.ntiles * P * sizeof(unsigned long long), stream));
         if (V.agg16)
             MGS_HIP(h, hipMemsetAsync(d_agg16, 0, ((size_t) p.ntiles << p.lpt_log) * sizeof(unsigned long long), stream));
-        const uint32_t grid = std::min<uint32_t>(p.ntiles, (uint32_t)(h->num_cus * V.blocks_per_cu));
+        uint32_t grid = std::min<uint32_t>(p.ntiles, (uint32_t)(h->num_cus * V.blocks_per_cu));
         unsigned long long *d_tab = nullptr;
-        if (V.agg16) {
+        if (sa) {
+            // streams layout: the sweep packs one round (the streams); workgroup 0 finds the rounds
+            if (!V.agg16 || noalloc) {
+                h->err = "the streams layout needs the production one-sweep kernel and the handle's own buffers";
+                return MGS_ERR_ARG;
+            }
+            if (V.tile > FR_MAX_TILE) {
+                h->err = "this tuning variant's tile is larger than the round finder's tables";
+                return MGS_ERR_ARG;
+            }
+            rc = ensure_round_tables(h, max_rounds, P, P, true);
+            if (rc) return rc;
+            p.f_rt = h->d_rt;
+            p.f_rt_start = p.f_rt + ((size_t) max_rounds + 1) * P;
+            p.rt = p.f_rt_start + ((size_t) max_rounds + 1);
+            p.rt_start = p.rt + 2 * (size_t) P;
+            p.clip_out = p.rt_start + 2;
+            p.max_rounds = 1;
+            p.finder = 1;
+            p.f_max_rounds = max_rounds;
+            p.f_cap = (unsigned long long) (D.buf_size >> 4);
+            d_tab = h->d_rtab;
+            MGS_HIP(h, hipMemsetAsync(h->d_rt, 0, round_table_words(max_rounds, P, true) * sizeof(unsigned long long), stream));
+            grid = std::min<uint32_t>(p.ntiles, (uint32_t) (h->num_cus * V.blocks_per_cu) - 1u) + 1u;
+        }
+        else if (V.agg16) {
             // the round-cutting kernel: round table + result table
             if (noalloc) {
                 unsigned long long *base = reinterpret_cast<unsigned long long *>(h->d_noalloc + kNoallocCtrlBytes);
@@ -682,7 +748,20 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         MGS_HIP(h, hipEventRecord(h->ev0, stream));
         hipLaunchKernelGGL(V.kernel[p.nbits], dim3(grid), dim3(V.threads), 0, stream, p);
         MGS_HIP(h, hipEventRecord(h->ev1, stream));
-        if (V.agg16) {
+        if (sa) {
+            // the sweep's one round into a scratch table (its clip words are what matters), then the rounds
+            unsigned long long *d_tab1 = d_tab + os_stab_words(max_rounds, (uint32_t) P) - os_rtab_words(1, (uint32_t) P);
+            hipLaunchKernelGGL(k_os_rounds_final, dim3(1), dim3(256), 0, stream, p, (uint32_t) P,
+                               (uint32_t) (D.rank >= 0 ? D.rank : 0), d_tab1);
+            const size_t items = (size_t) max_rounds * ((size_t) P + 1);
+            hipLaunchKernelGGL(k_os_streams_final, dim3((unsigned) std::min<size_t>(256, (items + 255) / 256)), dim3(256), 0,
+                               stream, p, (uint32_t) P, (uint32_t) (D.rank >= 0 ? D.rank : 0), d_tab);
+            MGS_HIP(h, hipMemcpyAsync(h->h_rtab, d_tab, os_stab_words(max_rounds, (uint32_t) P) * sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, stream));
+            h->pending_rounds = max_rounds;
+            h->pending_streams = true;
+        }
+        else if (V.agg16) {
             const size_t items = (size_t) max_rounds * ((size_t) P + 1);
             hipLaunchKernelGGL(k_os_rounds_final, dim3((unsigned) std::min<size_t>(256, (items + 255) / 256)), dim3(256), 0,
                                stream, p, (uint32_t) P, (uint32_t) (D.rank >= 0 ? D.rank : 0), d_tab);
@@ -710,7 +789,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         }
         if (osv) {
             const bool legacy = image_kernel;
-            if (legacy && max_rounds != 1) {
+            if (legacy && max_rounds != 1 && !sa) {
                 h->err = "the LDS-image kernel packs one round per call";
                 return MGS_ERR_ARG;
             }
@@ -746,7 +825,21 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             c.ctrl = d_ctrl;
             MGS_HIP(h, hipMemsetAsync(d_status, 0, (size_t) c.ntiles * columns * sizeof(unsigned long long), stream));
             MGS_HIP(h, hipMemsetAsync(d_agg16, 0, ((size_t) c.ntiles << c.lpt_log) * sizeof(unsigned long long), stream));
-            const uint32_t grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2));
+            uint32_t grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2));
+            if (sa) {
+                // streams layout: the sweep packs one round (the streams); workgroup 0 finds the rounds
+                rc = ensure_round_tables(h, max_rounds, columns, P, true);
+                if (rc) return rc;
+                c.f_rt = h->d_rt;
+                c.f_rt_start = c.f_rt + ((size_t) max_rounds + 1) * columns;
+                c.clip_out = c.f_rt_start + ((size_t) max_rounds + 1) + 2 * ((size_t) columns + 1);
+                c.finder = 1;
+                c.f_max_rounds = max_rounds;
+                c.f_cap = (unsigned long long) D.buf_size;
+                MGS_HIP(h, hipMemsetAsync(h->d_rt, 0, round_table_words(max_rounds, columns, true) * sizeof(unsigned long long),
+                                          stream));
+                grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2) - 1u) + 1u;
+            }
             const mgs_layout &L = D.layout;
             // layout mode 1: ONE string key and a fixed-width or absent value
             const int lm = (L.val_kind == MGS_VAL_CSTR) ? 0 : (L.key_kind == MGS_KEY_CSTR ? (L.key_count == 1 ? 1 : 0) : 2);
@@ -763,6 +856,16 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                 hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
                 if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
                 hipLaunchKernelGGL(k_osv_finalize, dim3(1), dim3(64), 0, stream, q);
+                if (sa) {
+                    const size_t items = (size_t) max_rounds * ((size_t) P + 1);
+                    hipLaunchKernelGGL(k_os_streams_final, dim3((unsigned) std::min<size_t>(256, (items + 255) / 256)),
+                                       dim3(256), 0, stream, c, (uint32_t) P, (uint32_t) P, h->d_rtab);
+                    MGS_HIP(h, hipMemcpyAsync(h->h_rtab, h->d_rtab,
+                                              os_stab_words(max_rounds, (uint32_t) P) * sizeof(unsigned long long),
+                                              hipMemcpyDeviceToHost, stream));
+                    h->pending_rounds = max_rounds;
+                    h->pending_streams = true;
+                }
             }
             else {
                 // the direct kernel: round table + result table, as for 16-byte records
@@ -917,7 +1020,7 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
                      "(records too long); use mgs_pack_device";
             return MGS_ERR_RECORD_SIZE;
         }
-        if (h->pending_rounds > 1) {
+        if (h->pending_rounds > 1 || h->pending_streams) {
             h->err = "records too long for the one-sweep kernel's LDS staging: pack this batch round by round";
             return MGS_ERR_RECORD_SIZE;
         }
@@ -954,8 +1057,9 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
         out->local_records = tab[3];
         out->local_bytes = (int64_t) tab[4];
         for (int b = 0; b < P; b++) out->send_offset[b] = (int64_t) tab[OS_RTAB_HEAD + 3 * R + b];
-        if (R != 1 && !rounds_caller) {
-            h->err = "mgs_pack_result: the call in flight packs several rounds (use mgs_pack_rounds_result)";
+        if ((R != 1 || h->pending_streams) && !rounds_caller) {
+            h->err = "mgs_pack_result: the call in flight packs several rounds (use mgs_pack_rounds_result / "
+                     "mgs_pack_streams_result)";
             return MGS_ERR_STATE;
         }
     }
@@ -968,7 +1072,7 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
         const uint64_t recs = out->next - h->pending_start;
         int64_t bytes = out->local_bytes;
         for (int b = 0; b < P; b++) bytes += out->send_offset[b] - h->pending_init[b];
-        if (recs > 0 && bytes > 0 && h->pending_rounds <= 1) h->ov_bytes_per_record = (double) bytes / (double) recs;
+        if (recs > 0 && bytes > 0 && h->pending_rounds <= 1 && !h->pending_streams) h->ov_bytes_per_record = (double) bytes / (double) recs;
         if (h->pending_osv) h->ov_shrink = 0; // a one-sweep kernel served the call: the length alone decides again
     }
     return MGS_OK;
@@ -1026,8 +1130,31 @@ int mgs_pack_rounds_device_async(mgs_handle *h, const void *d_records, const uin
                         d_dest_out, in_kernel, stream, false, max_rounds, image_stride);
 }
 
+static int rounds_result_impl(mgs_handle *h, mgs_rounds *out, uint64_t *round_next, int64_t *round_send_offset,
+                              int64_t *round_base, uint64_t *round_local_records, int64_t *round_local_bytes);
+
 int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next, int64_t *round_send_offset,
                            uint64_t *round_local_records, int64_t *round_local_bytes)
+{
+    if (h && h->pending && h->pending_streams) {
+        h->err = "mgs_pack_rounds_result: the call in flight uses the streams layout (use mgs_pack_streams_result)";
+        return MGS_ERR_STATE;
+    }
+    return rounds_result_impl(h, out, round_next, round_send_offset, nullptr, round_local_records, round_local_bytes);
+}
+
+int mgs_pack_streams_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next, int64_t *round_send_offset,
+                            int64_t *round_base, uint64_t *round_local_records, int64_t *round_local_bytes)
+{
+    if (h && h->pending && !h->pending_streams && !h->pending_empty) {
+        h->err = "mgs_pack_streams_result: the call in flight does not use the streams layout";
+        return MGS_ERR_STATE;
+    }
+    return rounds_result_impl(h, out, round_next, round_send_offset, round_base, round_local_records, round_local_bytes);
+}
+
+static int rounds_result_impl(mgs_handle *h, mgs_rounds *out, uint64_t *round_next, int64_t *round_send_offset,
+                              int64_t *round_base, uint64_t *round_local_records, int64_t *round_local_bytes)
 {
     if (!h || !out) return MGS_ERR_ARG;
     if (!h->pending) {
@@ -1046,6 +1173,10 @@ int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next,
         if (round_local_bytes) round_local_bytes[0] = 0;
         if (round_send_offset)
             for (int b = 0; b < P; b++) round_send_offset[b] = h->pending_init[b];
+        if (round_base)
+            for (int b = 0; b < P; b++) round_base[b] = h->pending_base[b];
+        if (h->pending_streams && round_send_offset)
+            for (int b = 0; b < P; b++) round_send_offset[b] = h->pending_init[b] - h->pending_base[b];
         return MGS_OK;
     }
     if (R == 0) {
@@ -1081,8 +1212,59 @@ int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next,
         if (round_send_offset)
             for (int b = 0; b < P; b++)
                 round_send_offset[(size_t) k * P + b] = (int64_t) tab[OS_RTAB_HEAD + 3 * (size_t) R + (size_t) k * P + b];
+        if (round_base && h->pending_streams)
+            for (int b = 0; b < P; b++)
+                round_base[(size_t) k * P + b] =
+                    (int64_t) tab[OS_RTAB_HEAD + 3 * (size_t) R + (size_t) R * P + (size_t) k * P + b];
     }
     return MGS_OK;
+}
+
+int mgs_pack_streams_device_async(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
+                                  uint64_t start, const int64_t *stream_fill, const int64_t *open_round_base,
+                                  void *d_streams, int64_t stream_cap, uint32_t max_rounds, void *d_local_out,
+                                  int64_t local_cap, uint8_t *d_dest_out, void *stream)
+{
+    if (!h) return MGS_ERR_ARG;
+    if (max_rounds < 1 || stream_cap < 1) {
+        h->err = "mgs_pack_streams_device: max_rounds >= 1 and stream_cap >= 1 required";
+        return MGS_ERR_ARG;
+    }
+    const mgs_desc &D = h->desc;
+    const bool os16 = h->fixed_len == 16 && D.nranks <= OS_MAXP && D.layout.key_kind == MGS_KEY_FIXED
+                      && D.layout.key_bytes <= 16;
+    const bool osv = D.nranks + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
+                     && (h->fixed_len == 0 || ov_pick_k_legacy((double) h->fixed_len) != 0);
+    if (!os16 && !osv) {
+        h->err = "mgs_pack_streams_device: at most 64 ranks (63 with a local rank unless records are 16 bytes), fixed "
+                 "widths up to 79 bytes or variable width";
+        return MGS_ERR_ARG;
+    }
+    const StreamsArgs sa = {stream_cap, open_round_base};
+    for (int b = 0; b < MGS_MAX_RANKS; b++) {
+        const int64_t fill = (stream_fill && b < D.nranks && b != D.rank) ? stream_fill[b] : 0;
+        h->pending_base[b] = (open_round_base && b < D.nranks && b != D.rank) ? open_round_base[b] : fill;
+    }
+    const int rc = pack_enqueue(h, d_records, d_rec_off, n_end, start, stream_fill, d_streams, d_local_out, local_cap,
+                                d_dest_out, MGS_ALGO_AUTO, stream, false, max_rounds, 0, &sa);
+    if (rc == MGS_OK && h->pending_empty) h->pending_streams = true;
+    return rc;
+}
+
+int mgs_pack_streams_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
+                            uint64_t start, const int64_t *stream_fill, const int64_t *open_round_base, void *d_streams,
+                            int64_t stream_cap, uint32_t max_rounds, void *d_local_out, int64_t local_cap,
+                            uint8_t *d_dest_out, void *stream, mgs_rounds *out, uint64_t *round_next,
+                            int64_t *round_send_offset, int64_t *round_base, uint64_t *round_local_records,
+                            int64_t *round_local_bytes)
+{
+    if (!h || !out) return MGS_ERR_ARG;
+    const int rc = mgs_pack_streams_device_async(h, d_records, d_rec_off, n_end, start, stream_fill, open_round_base,
+                                                 d_streams, stream_cap, max_rounds, d_local_out, local_cap, d_dest_out,
+                                                 stream);
+    if (rc) return rc;
+    return mgs_pack_streams_result(h, out, round_next, round_send_offset, round_base, round_local_records,
+                                   round_local_bytes);
 }
 
 int mgs_pack_rounds_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
@@ -1683,6 +1865,13 @@ int mgs_debug_stats(mgs_handle *h, uint64_t out[8])
 }
 
 int mgs_get_tuning(const mgs_handle *h) { return h ? h->os_variant : -1; }
+
+int mgs_finder_stats(mgs_handle *h, uint64_t out[4])
+{
+    if (!h || !out) return MGS_ERR_ARG;
+    for (int i = 0; i < 4; i++) out[i] = h->h_ctrl->head.fstats[i];
+    return MGS_OK;
+}
 
 const char *mgs_tuning_name(int variant)
 {

@@ -171,11 +171,13 @@ struct CtrlHead {
     int32_t error;                // first mgs_status raised on the device
     uint32_t fallback;            // byte-granular one-sweep path: 1 = a tile does not fit LDS, run the generic path
     uint32_t rounds_cut;          // round-cutting kernels: round cuts published so far (= index of the last round begun)
-    uint32_t pad0;
+    uint32_t f_cuts;              // streams layout: round cuts found by the round finder
     uint64_t part_base[MGS_MAX_RANKS]; // device address of each partition's byte 0
     int64_t part_cap[MGS_MAX_RANKS];   // capacity in bytes
     int64_t part_init[MGS_MAX_RANKS];  // bytes already there
+    int64_t round_base0[MGS_MAX_RANKS]; // streams layout: byte of each stream at which the open round began
     unsigned long long stats[8];       // diagnostic builds only (see OSV_STATS)
+    unsigned long long fstats[4];      // round finder: its wall time (100 MHz ticks), cycles searching / hashing / walking
 };
 
 struct Ctrl {

@@ -81,6 +81,19 @@ struct OsParams {
     unsigned long long *rt_start;
     uint32_t max_rounds;
     uint64_t image_stride;
+    // Streams layout (mgs_round_finder.h): the sweep packs ONE round whose partitions are
+    // the caller's destination streams; workgroup 0 of the grid does not sweep but trails
+    // the chained scan and finds where the reference's rounds (partitions of f_cap units)
+    // begin inside the streams: f_rt / f_rt_start are a round table of f_max_rounds + 1
+    // entries in the format of rt / rt_start, f_cuts receives the number of cuts found.
+    uint32_t finder; // 1: workgroup 0 is the round finder
+    uint32_t f_max_rounds;
+    unsigned long long f_cap;
+    unsigned long long *f_rt;
+    unsigned long long *f_rt_start;
+    // optional, written by the kernel that finishes a one-round call: [0] = records of this
+    // call that were packed, [1 + c] = units of column c before the first record that was not
+    unsigned long long *clip_out;
 };
 
 constexpr unsigned long long OS_RT_VALID = 1ull << 63;

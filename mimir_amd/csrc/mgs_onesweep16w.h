@@ -27,6 +27,7 @@
 #define MGS_ONESWEEP16W_H
 
 #include "mgs_onesweep16.h"
+#include "mgs_round_finder.h"
 
 namespace mgs {
 
@@ -500,6 +501,14 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
     const uint32_t P = p.P;
     constexpr uint32_t nbits = NB;
 
+    if (p.finder && blockIdx.x == 0) {
+        // streams layout: this workgroup finds the rounds instead of sweeping
+        static_assert(sizeof(FinderLds) <= sizeof(srec), "the finder's tables live in the tile image");
+        FinderSrc16 src{p};
+        os_round_finder(p, P, src, reinterpret_cast<FinderLds *>(srec), tid, THREADS);
+        return;
+    }
+
     if (tid < OS_MAXP) {
         const bool live = (uint32_t) tid < P;
         pbase[tid] = live ? p.ctrl->head.part_base[tid] : 0ull;
@@ -832,7 +841,9 @@ __global__ __launch_bounds__(256) void k_os_rounds_final(OsParams p, uint32_t P,
         tab[2] = nx - lrec;
         tab[3] = lrec;
         tab[4] = lbytes;
+        if (p.clip_out) p.clip_out[0] = nx;
     }
+    if (p.clip_out && gtid < PC) p.clip_out[1 + gtid] = end_of(n_rounds - 1, gtid);
 }
 
 } // namespace mgs

@@ -184,6 +184,51 @@ __global__ void k_osv_check(OvParams q)
         __hip_atomic_store(&q.os.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The round finder's view of a tile of byte-granular records (mgs_round_finder.h): the
+// tile's span is parked in the staging buffer, key lengths and hashes are read from there.
+struct FinderSrcV {
+    const OvParams &q;
+    uint8_t *sin;
+    uint64_t s = 0;     // first byte of the staged span in blob
+    uint32_t shift = 0; // the span starts `shift` bytes into the staging buffer
+    uint64_t span = 0;
+    __device__ void stage(uint32_t tile, int tid, int nthreads)
+    {
+        const uint64_t T = q.os.tile_records;
+        const uint64_t i0 = (uint64_t) tile * T, i1 = min(q.n, i0 + T);
+        s = ov_offset(q, i0);
+        const uint64_t e = ov_offset(q, i1);
+        const uintptr_t a0 = ((uintptr_t) q.blob + s) & ~(uintptr_t) 15;
+        shift = (uint32_t) (((uintptr_t) q.blob + s) & 15u);
+        span = (e >= s ? e - s : 0) + shift;
+        if (span > (uint64_t) OV_IN_BYTES) span = 0; // k_osv_check has sent such a call to the generic path
+        const uint32_t nch = (uint32_t) ((span + 15) >> 4);
+        __syncthreads(); // the previous tile's bytes are no longer read
+        for (uint32_t ch = (uint32_t) tid; ch < nch; ch += (uint32_t) nthreads)
+            reinterpret_cast<uint4 *>(sin)[ch] = reinterpret_cast<const uint4 *>(a0)[ch];
+        __syncthreads();
+    }
+    __device__ void info(uint32_t tile, uint32_t i, uint32_t &d, uint32_t &u, bool &valid) const
+    {
+        const uint64_t T = q.os.tile_records;
+        const uint64_t idx = (uint64_t) tile * T + i;
+        valid = i < T && idx < q.n;
+        d = 0;
+        u = 0;
+        if (!valid) return;
+        const uint64_t o0 = ov_offset(q, idx), o1 = ov_offset(q, idx + 1);
+        const uint32_t len = (uint32_t) (o1 - o0);
+        uint32_t klen = 0;
+        const uint64_t r = o0 - s + shift;
+        if (o1 <= o0 || o0 < s || o1 - o0 > GEN_MAX_RECORD || r + len > span || !gen_key_len(q.lay, sin + r, len, klen)) {
+            valid = false; // reported by the sweep
+            return;
+        }
+        d = fastmod(hashlittle_bytes(sin + r, klen), q.os.fm);
+        u = len;
+    }
+};
+
 // LM (layout mode) spares the per-record layout decisions: 1 = string key(s) and a
 // fixed-width or absent value (key = the record minus the value, ends with a NUL);
 // 2 = fixed-width key and a fixed-width or absent value; 0 = any layout.
@@ -209,6 +254,14 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t P = q.P;   // destinations
     const uint32_t PC = p.P;  // chain columns
+
+    if (p.finder && blockIdx.x == 0) {
+        // streams layout: this workgroup finds the rounds instead of sweeping
+        static_assert(sizeof(FinderLds) <= sizeof(sout), "the finder's tables live in the image buffer");
+        FinderSrcV src{q, sin};
+        os_round_finder(p, P, src, reinterpret_cast<FinderLds *>(sout), tid, THREADS);
+        return;
+    }
 
     for (int j = tid; j < 2 * WORKERS * OS_MAXP; j += THREADS) wcnt[j] = 0;
     if (tid == 0) {
@@ -799,6 +852,11 @@ __global__ __launch_bounds__(64) void k_osv_finalize(OvParams q)
     }
     __syncthreads();
     const unsigned long long mytot = before + run[lane];
+    if (p.clip_out) {
+        if (lane == 0) p.clip_out[0] = e;
+        if ((uint32_t) lane < P) p.clip_out[1 + lane] = mytot;
+        else if ((uint32_t) lane < PC) p.clip_out[1 + lane] = before + lrun[0];
+    }
     if (live) {
         if ((int32_t) lane == p.self) {
             res->send_offset[lane] = 0;

@@ -1,0 +1,370 @@
+// Streams layout: where do the reference's rounds begin?
+//
+// CollectiveShuffler::write (src/collectiveshuffler.h:131-166) ends a round before the
+// first record that does not fit its partition of buf_size bytes, exchanges, and starts
+// every partition again from empty.  A sweep that has to know the current round before
+// it may store a record stalls at every cut: the tiles behind the cut wait for the one
+// tile that holds it.  In the streams layout the sweep does not know about rounds at
+// all.  It packs the whole batch as ONE round whose "partitions" are the caller's
+// destination streams (as long as the caller likes), and the rounds are views into the
+// streams: with C_b(r) the units of column b before record r (the chained scan's running
+// totals, never reset) and B_k[b] = C_b(first record of round k), round k's partition b
+// is bytes [B_k[b], B_{k+1}[b]) of stream b -- byte for byte what the reference's send
+// buffer holds for that partition in its k-th exchange.
+//
+// What is left is to find the B_k.  Workgroup 0 of the sweep's grid does that instead of
+// sweeping: it trails the chained scan, reading the inclusive prefixes the scan waves
+// publish (OsParams::status).  Round k is cut at the first record r (destination b, not
+// the local rank) with C_b(r) + size(r) > B_k[b] + capacity.  Totals only grow, so the
+// tile that holds the cut is the first one whose inclusive prefix exceeds a limit: a
+// monotone predicate, found by probing FR_LOOK * (64 / columns) tiles per step at a
+// spacing that follows the previous round's length.  That one tile is then hashed again
+// (all waves of the workgroup, a row of 64 records each) and walked for the exact
+// record; B_{k+1} and the record's index go to the round table.  The sweep never waits
+// for the finder, so the two cannot deadlock whatever the dispatch order; the finder
+// waits for the sweep with a bounded spin and leaves when the sweep has raised an error.
+#ifndef MGS_ROUND_FINDER_H
+#define MGS_ROUND_FINDER_H
+
+#include "mgs_onesweep16.h"
+
+namespace mgs {
+
+constexpr int FR_LOOK = 8;                 // status loads in flight per probe step
+constexpr int FR_MAX_ROWS = 56;            // rows of 64 records in the largest tile (3584 records)
+constexpr int FR_MAX_TILE = FR_MAX_ROWS * 64;
+constexpr uint32_t FR_EXIT = 0xFFFFFFFFu;
+
+struct FinderLds {
+    uint32_t rowcnt[FR_MAX_ROWS][OS_MAXP]; // units per (row of the tile, column)
+    uint32_t units[FR_MAX_TILE];           // units of every record of the tile (0: no record)
+    uint8_t dest[FR_MAX_TILE];             // its destination (0xFF: no record)
+    unsigned long long cnt[OS_MAXP];       // units per column of a row's lanes before a cut
+    volatile uint32_t cmd[4];              // [0] tile to examine next, or FR_EXIT
+};
+
+// 16-byte records straight from global memory.
+struct FinderSrc16 {
+    const OsParams &p;
+    __device__ void stage(uint32_t, int, int) {}
+    __device__ void info(uint32_t tile, uint32_t i, uint32_t &d, uint32_t &u, bool &valid) const
+    {
+        const uint64_t idx = (uint64_t) tile * p.tile_records + i;
+        valid = i < p.tile_records && idx < p.n;
+        d = 0;
+        u = 1;
+        if (valid) {
+            const uint4 r = p.rec[idx];
+            d = fastmod(hash_rec16(r.x, r.y, r.z, r.w, p.klen), p.fm);
+        }
+    }
+};
+
+template <class Src>
+__device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, Src &src, FinderLds *x, int tid,
+                                             int nthreads)
+{
+    const int lane = tid & 63, w = tid >> 6, nw = nthreads >> 6;
+    const uint32_t PC = p.P; // columns of the chained scan: P destinations (+ the local record count)
+    const uint32_t rows = (p.tile_records + 63u) / 64u;
+    const bool extra_col = PC > P; // column P counts the records of the local rank
+
+    // ---- wave 0: the state of the search, lane = column
+    const bool live = (uint32_t) lane < PC;
+    const bool is_part = (uint32_t) lane < P && lane != p.self;
+    unsigned long long lim = ~0ull;
+    if (is_part) lim = (unsigned long long) (p.ctrl->head.round_base0[lane] >> p.unit_shift) + p.f_cap;
+    uint32_t k = 0;       // cuts found
+    int64_t lo = -1;      // tiles 0 .. lo hold no cut of the current round
+    int64_t last_cut = 0; // tile of the previous cut
+    // probe geometry: lane = (slot j of a load, column c)
+    const uint32_t npad = p.nbits_pad, Pp = 1u << npad, tpl = 64u >> npad, M = (uint32_t) FR_LOOK * tpl;
+    const uint32_t j = (uint32_t) lane >> npad, c = (uint32_t) lane & (Pp - 1u);
+    const bool col_ok = c < PC, c_part = c < P && (int32_t) c != p.self;
+    const uint64_t gmask = (Pp == 64) ? ~0ull : ((1ull << Pp) - 1ull);
+    const uint32_t gshift = j << npad;
+    uint64_t S = 16; // spacing of the probes, in tiles
+    bool finished = false;
+    const unsigned long long wall0 = wall_clock64();
+    unsigned long long cy_search = 0, cy_hash = 0, cy_walk = 0;
+
+    for (;;) {
+        unsigned long long hi_val = 0; // lane = column: inclusive prefix of the tile that holds the cut
+        unsigned long long cy0 = __builtin_readcyclecounter();
+        if (w == 0) {
+            uint32_t found = FR_EXIT;
+            if (!finished) {
+                const unsigned long long lim_c = (unsigned long long) __shfl((long long) lim, (int) c);
+                int64_t hi = (int64_t) p.ntiles; // first tile known to hold a cut (ntiles: none known)
+                uint32_t idle = 0;
+                while (hi - lo > 1) {
+                    const int64_t top = hi - 1; // probes stay inside (lo, hi)
+                    unsigned long long v[FR_LOOK];
+#pragma unroll
+                    for (int q = 0; q < FR_LOOK; q++) {
+                        int64_t t = lo + (int64_t) (((uint64_t) q * tpl + j + 1u) * S);
+                        t = t < top ? t : top;
+                        v[q] = col_ok ? os_load_status(p.status + (uint64_t) t * PC + c) : OS_FLAG_INCL;
+                    }
+                    // the first probed tile that is not known to lie before the cut
+                    bool hit = false, hit_cross = false;
+                    uint32_t slot = 0;
+                    unsigned long long hv = 0;
+#pragma unroll
+                    for (int q = 0; q < FR_LOOK; q++) {
+                        const bool pub = (v[q] >> 62) == 2;
+                        const bool crossing = pub && c_part && (v[q] & OS_VALUE_MASK) > lim_c;
+                        const uint64_t m_pub = __ballot(pub), m_cr = __ballot(crossing);
+                        const bool s_pub = ((m_pub >> gshift) & gmask) == gmask;
+                        const bool s_cr = ((m_cr >> gshift) & gmask) != 0;
+                        const uint64_t nbm = __ballot(!s_pub || s_cr);
+                        if (nbm && !hit) {
+                            const uint32_t fj = (uint32_t) (__ffsll((unsigned long long) nbm) - 1) >> npad;
+                            hit = true;
+                            slot = (uint32_t) q * tpl + fj;
+                            hit_cross = ((__ballot(s_pub && s_cr) >> (fj << npad)) & 1ull) != 0;
+                            hv = (unsigned long long) __shfl((long long) v[q], (int) ((fj << npad) | ((uint32_t) lane & (Pp - 1u))));
+                        }
+                    }
+                    if (!hit) { // every probe lies before the cut
+                        int64_t t = lo + (int64_t) ((uint64_t) M * S);
+                        lo = t < top ? t : top;
+                        if (S < (1ull << 24)) S *= 2;
+                        idle = 0;
+                        continue;
+                    }
+                    int64_t t_f = lo + (int64_t) (((uint64_t) slot + 1u) * S);
+                    t_f = t_f < top ? t_f : top;
+                    int64_t t_prev = lo + (int64_t) ((uint64_t) slot * S);
+                    t_prev = t_prev < top ? t_prev : top;
+                    if (t_prev >= t_f) t_prev = lo; // clamped probes of one tile: nothing new is known
+                    if (hit_cross) {
+                        hi = t_f;
+                        hi_val = hv & OS_VALUE_MASK;
+                        if (slot) lo = t_prev > lo ? t_prev : lo;
+                        const uint64_t gap = (uint64_t) (hi - lo - 1);
+                        S = (gap + M - 1) / M;
+                        if (S == 0) S = 1;
+                        idle = 0;
+                        continue;
+                    }
+                    // not published yet: the sweep has not got there
+                    if (slot && t_prev > lo) {
+                        lo = t_prev;
+                        idle = 0;
+                    }
+                    if (++idle > OS_SPIN_LIMIT) {
+                        raise_error(p.ctrl, MGS_ERR_TIMEOUT);
+                        finished = true;
+                        break;
+                    }
+                    if ((idle & 63u) == 0
+                        && __hip_atomic_load(&p.ctrl->head.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        finished = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                if (!finished && hi < (int64_t) p.ntiles) found = (uint32_t) hi;
+            }
+            if (lane == 0) x->cmd[0] = found;
+        }
+        __syncthreads();
+        const uint32_t tile = x->cmd[0];
+        cy_search += __builtin_readcyclecounter() - cy0;
+        if (tile == FR_EXIT) break;
+        cy0 = __builtin_readcyclecounter();
+
+        // ---- every wave: destinations and units of the tile's records, units per (row, column)
+        src.stage(tile, tid, nthreads);
+        for (uint32_t r = (uint32_t) w; r < rows; r += (uint32_t) nw) {
+            x->rowcnt[r][lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t i = r * 64u + (uint32_t) lane;
+            uint32_t d, u;
+            bool valid;
+            src.info(tile, i, d, u, valid);
+            x->dest[i] = valid ? (uint8_t) d : (uint8_t) 0xFF;
+            x->units[i] = valid ? u : 0u;
+            if (valid) {
+                atomicAdd(&x->rowcnt[r][d], u);
+                if (extra_col && (int32_t) d == p.self) atomicAdd(&x->rowcnt[r][P], 1u);
+            }
+        }
+        __syncthreads();
+        cy_hash += __builtin_readcyclecounter() - cy0;
+        cy0 = __builtin_readcyclecounter();
+
+        // ---- wave 0: every cut of the tile, in emit order
+        if (w == 0) {
+            unsigned long long tot = 0;
+            for (uint32_t r = 0; r < rows; r++) tot += x->rowcnt[r][lane];
+            unsigned long long run = hi_val - tot; // lane = column: units before the tile
+            uint32_t r0 = 0;
+            for (;;) {
+                // the first row at whose end a partition is past its limit
+                uint32_t rs = rows;
+                unsigned long long acc = run;
+                for (uint32_t r = r0; r < rows; r++) {
+                    const unsigned long long cn = x->rowcnt[r][lane];
+                    if (__ballot(is_part && acc + cn > lim)) {
+                        rs = r;
+                        break;
+                    }
+                    acc += cn;
+                }
+                if (rs == rows) break; // no (further) cut in this tile
+                run = acc;
+                const uint32_t i = rs * 64u + (uint32_t) lane;
+                const uint32_t d = x->dest[i], u = x->units[i];
+                const bool act = d != 0xFFu;
+                // units of each record's column up to and including the record
+                unsigned long long upto = 0;
+                uint64_t rem = __ballot(act);
+                while (rem) { // one trip per distinct destination of the row
+                    const int leader = __ffsll((unsigned long long) rem) - 1;
+                    const uint32_t b = (uint32_t) __shfl((int) d, leader);
+                    const bool inb = act && d == b;
+                    const uint32_t inc = wave_incl_scan_u32(inb ? u : 0u, lane);
+                    const unsigned long long run_b = (unsigned long long) __shfl((long long) run, (int) b);
+                    if (inb) upto = run_b + inc;
+                    rem &= ~__ballot(inb);
+                }
+                const unsigned long long lim_d = (unsigned long long) __shfl((long long) lim, (int) (d & 63u));
+                const uint64_t om = __ballot(act && upto > lim_d);
+                if (!om) { // cannot happen: the row's totals said otherwise
+                    r0 = rs + 1;
+                    continue;
+                }
+                const int fl = __ffsll((unsigned long long) om) - 1;
+                // totals at record (rs, fl), the first of the next round
+                x->cnt[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (act && lane < fl) {
+                    atomicAdd(&x->cnt[d], (unsigned long long) u);
+                    if (extra_col && (int32_t) d == p.self) atomicAdd(&x->cnt[P], 1ull);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long before = x->cnt[lane];
+                const unsigned long long nb = run + before;
+                k++;
+                if (live) p.f_rt[(uint64_t) k * PC + lane] = OS_RT_VALID | nb;
+                if (lane == 0)
+                    p.f_rt_start[k] = OS_RT_VALID | ((uint64_t) tile * p.tile_records + (uint64_t) rs * 64u + (uint32_t) fl);
+                // a record that does not fit an empty partition (src/collectiveshuffler.h:156-159)
+                const uint32_t uf = (uint32_t) __shfl((int) u, fl);
+                if ((unsigned long long) uf > p.f_cap) {
+                    raise_error(p.ctrl, MGS_ERR_RECORD_SIZE);
+                    finished = true;
+                    break;
+                }
+                if (k >= p.f_max_rounds) { // the end marker: the caller's tables are full
+                    finished = true;
+                    break;
+                }
+                if (is_part) lim = nb + p.f_cap;
+                // the rest of the row belongs to the new round
+                if (lane < fl) {
+                    x->dest[i] = 0xFF;
+                    x->units[i] = 0;
+                }
+                x->rowcnt[rs][lane] -= (uint32_t) before;
+                __builtin_amdgcn_wave_barrier();
+                run = nb;
+                r0 = rs;
+            }
+            // next search: the probes span 1.25 times the length of the round just found
+            const uint64_t len = (uint64_t) ((int64_t) tile - last_cut) + 1u;
+            S = (len + len / 4 + M - 1) / M;
+            if (S == 0) S = 1;
+            last_cut = (int64_t) tile;
+            lo = (int64_t) tile;
+            cy_walk += __builtin_readcyclecounter() - cy0;
+        }
+        __syncthreads(); // the tile's tables are free again
+    }
+    if (w == 0 && lane == 0) {
+        p.ctrl->head.f_cuts = k;
+        p.ctrl->head.fstats[0] = wall_clock64() - wall0;
+        p.ctrl->head.fstats[1] = cy_search;
+        p.ctrl->head.fstats[2] = cy_hash;
+        p.ctrl->head.fstats[3] = cy_walk;
+    }
+}
+
+// Result table of a streams-layout call: the table of a round-cutting call (see
+// os_rtab_words) followed by
+//   [8 + 3R + R*P + k*P + b]  byte of stream b at which round k's partition begins
+__host__ __device__ inline size_t os_stab_words(uint32_t max_rounds, uint32_t P)
+{
+    return (size_t) 8 + (size_t) max_rounds * (3 + 2 * (size_t) P);
+}
+
+// After the sweep and the kernel that finished its one round (p.clip_out: the records that
+// were packed and the totals at that point): which of the finder's rounds were packed, and
+// the per-round arrays.  A round that begins at or after the first record that was not
+// packed is not reported; the last reported round is open.
+__global__ __launch_bounds__(256) void k_os_streams_final(OsParams p, uint32_t P, uint32_t lrec_col,
+                                                          unsigned long long *tab)
+{
+    const uint32_t PC = p.P, R = p.f_max_rounds;
+    const uint32_t K = p.ctrl->head.f_cuts < R ? p.ctrl->head.f_cuts : R;
+    const unsigned long long clip = p.clip_out[0];
+    // rounds that begin before record `clip` (starts grow with k)
+    uint32_t lo = 0, hi = K; // invariant: rounds 1..lo begin before clip, rounds hi+1..K do not
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) / 2;
+        if ((p.f_rt_start[mid] & ~OS_RT_VALID) < clip) lo = mid;
+        else hi = mid - 1;
+    }
+    const uint32_t m = lo + 1;
+    const bool marker = m > R; // round R begins before the clip: the tables are full, it is the end marker
+    const uint32_t n_rounds = marker ? R : m;
+    const unsigned long long nx = marker ? (p.f_rt_start[R] & ~OS_RT_VALID) : clip;
+    auto begin_of = [&](uint32_t k, uint32_t col) -> unsigned long long {
+        if (k) return p.f_rt[(uint64_t) k * PC + col] & ~OS_RT_VALID;
+        return (col < P && (int32_t) col != p.self) ? (unsigned long long) (p.ctrl->head.round_base0[col] >> p.unit_shift)
+                                                    : 0ull;
+    };
+    auto end_of = [&](uint32_t k, uint32_t col) -> unsigned long long {
+        if (k + 1 < m) return p.f_rt[(uint64_t) (k + 1) * PC + col] & ~OS_RT_VALID;
+        return p.clip_out[1 + col];
+    };
+    const size_t base_at = (size_t) 8 + 3 * (size_t) R + (size_t) R * P;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    for (uint64_t t = gtid; t < (uint64_t) n_rounds * (P + 1); t += gsz) {
+        const uint32_t k = (uint32_t) (t / (P + 1)), b = (uint32_t) (t % (P + 1));
+        if (b == P) {
+            const unsigned long long e = (k + 1 < n_rounds || marker) ? (p.f_rt_start[k + 1] & ~OS_RT_VALID) : clip;
+            tab[8 + k] = p.first + e;
+            unsigned long long lrec = 0, lbytes = 0;
+            if (p.self >= 0) {
+                lrec = end_of(k, lrec_col) - begin_of(k, lrec_col);
+                lbytes = (end_of(k, (uint32_t) p.self) - begin_of(k, (uint32_t) p.self)) << p.unit_shift;
+            }
+            tab[8 + R + k] = lrec;
+            tab[8 + 2 * (uint64_t) R + k] = lbytes;
+        }
+        else {
+            const bool self = (int32_t) b == p.self;
+            const unsigned long long u = self ? 0ull : end_of(k, b) - begin_of(k, b);
+            tab[8 + 3 * (uint64_t) R + (uint64_t) k * P + b] = u << p.unit_shift;
+            tab[base_at + (uint64_t) k * P + b] = self ? 0ull : begin_of(k, b) << p.unit_shift;
+        }
+    }
+    if (gtid == 0) {
+        unsigned long long lrec = 0, lbytes = 0;
+        if (p.self >= 0) {
+            lrec = end_of(n_rounds - 1, lrec_col);
+            lbytes = end_of(n_rounds - 1, (uint32_t) p.self) << p.unit_shift;
+        }
+        tab[0] = n_rounds;
+        tab[1] = p.first + nx;
+        tab[2] = nx - lrec;
+        tab[3] = lrec;
+        tab[4] = lbytes;
+    }
+}
+
+} // namespace mgs
+#endif

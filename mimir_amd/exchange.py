@@ -89,7 +89,7 @@ def exchange_round(send_image, send_offset_host, buf_size, recv_image, done=Fals
 
 
 def exchange_rounds(send_images, image_stride, round_send_offset, buf_size, recv_images,
-                    recv_stride, group=None):
+                    recv_stride, group=None, round_base=None):
     """The exchanges of a batch that was packed into many rounds at once
     (DevicePacker.pack_rounds): round k of every rank is the k-th exchange_kv of the
     reference (src/collectiveshuffler.h:587-674).  Ranks cut their rounds where their own
@@ -101,6 +101,11 @@ def exchange_rounds(send_images, image_stride, round_send_offset, buf_size, recv
     round_send_offset: host int64 array [R_mine, P]: bytes per partition and round
     recv_images      : uint8; the receive image of exchange k is written at
                        [k*recv_stride :], source 0's bytes, then source 1's, ...
+    round_base       : streams layout (DevicePacker.pack_streams): send_images holds P
+                       destination streams of buf_size bytes, image_stride is ignored, and
+                       round k's partition d begins at byte round_base[k, d] of stream d --
+                       the all-to-all-v's send displacement is d*buf_size + round_base[k, d]
+                       where the reference's is d*buf_size (src/collectiveshuffler.h:631-634)
     The counts of all rounds travel in one all-to-all (one row per round) instead of one
     per round; the payload goes round by round, each a grouped batch of point-to-point
     transfers straight out of the send image.  Returns (recv_count int64 [R, P], R)."""
@@ -132,7 +137,8 @@ def exchange_rounds(send_images, image_stride, round_send_offset, buf_size, recv
         for peer in range(P):
             sb = int(full[k, peer])
             if sb > 0 and peer != me:
-                o = k * image_stride + peer * buf_size
+                o = (k * image_stride + peer * buf_size if round_base is None
+                     else peer * buf_size + int(round_base[k][peer]))
                 ops.append(dist.P2POp(dist.isend, send_images[o:o + sb],
                                       dist.get_global_rank(group, peer) if group else peer, group=group))
         if ops:

@@ -34,8 +34,10 @@ class RoundResult:
 class RoundsResult:
     """Host copy of a many-round pack call: totals plus one row per round."""
 
-    def __init__(self, r, nxt, so, lrec, lbytes, nranks):
+    def __init__(self, r, nxt, so, lrec, lbytes, nranks, base=None):
         n = int(r.n_rounds)
+        # streams layout: byte of each destination stream at which the round's partition begins
+        self.round_base = None if base is None else base[:n * nranks].reshape(n, nranks).copy()
         self.n_rounds = n
         self.next = int(r.next)
         self.packed_records = int(r.packed_records)
@@ -103,6 +105,11 @@ class DevicePacker:
     def debug_stats(self):
         out = (C.c_uint64 * 8)()
         self._check(self.lib.mgs_debug_stats(self.h, out))
+        return list(out)
+
+    def finder_stats(self):
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.mgs_finder_stats(self.h, out))
         return list(out)
 
     def copy_calibration(self, src, dst, n_records):
@@ -179,6 +186,55 @@ class DevicePacker:
             self.h, C.byref(r), nxt.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p),
             lrec.ctypes.data_as(C.c_void_p), lbytes.ctypes.data_as(C.c_void_p)))
         return RoundsResult(r, nxt, so, lrec, lbytes, self.nranks)
+
+    def _streams_args(self, records, rec_off, n_end, start, stream_fill, open_round_base, streams, stream_cap,
+                      max_rounds, local_out, dest_out, stream):
+        keep = []
+
+        def host(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.int64)
+            assert a.shape[0] >= self.nranks
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        local_cap = local_out.numel() if local_out is not None else 0
+        return (self.h, _ptr(records), _ptr(rec_off), n_end, start, host(stream_fill), host(open_round_base),
+                _ptr(streams), int(stream_cap), max_rounds, _ptr(local_out), local_cap, _ptr(dest_out),
+                C.c_void_p(stream)), keep
+
+    def pack_streams(self, records, n_end, streams, stream_cap, max_rounds, start=0, rec_off=None,
+                     stream_fill=None, open_round_base=None, local_out=None, dest_out=None, stream=None):
+        """mgs_pack_streams_device: records [start, n_end) appended to nranks destination
+        streams (stream b at streams[b * stream_cap:]); the reference's rounds come back as
+        views: round k's partition b is stream b's bytes [round_base[k, b], + round_send_offset[k, b])."""
+        args, _keep = self._streams_args(records, rec_off, n_end, start, stream_fill, open_round_base, streams,
+                                         stream_cap, max_rounds, local_out, dest_out, stream)
+        nxt, so, lrec, lbytes = self._rounds_buffers(max_rounds)
+        base = np.zeros(max_rounds * self.nranks, dtype=np.int64)
+        r = capi.Rounds()
+        self._check(self.lib.mgs_pack_streams_device(
+            *args, C.byref(r), nxt.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p),
+            base.ctypes.data_as(C.c_void_p), lrec.ctypes.data_as(C.c_void_p), lbytes.ctypes.data_as(C.c_void_p)))
+        return RoundsResult(r, nxt, so, lrec, lbytes, self.nranks, base)
+
+    def pack_streams_async(self, records, n_end, streams, stream_cap, max_rounds, start=0, rec_off=None,
+                           stream_fill=None, open_round_base=None, local_out=None, dest_out=None, stream=None):
+        args, _keep = self._streams_args(records, rec_off, n_end, start, stream_fill, open_round_base, streams,
+                                         stream_cap, max_rounds, local_out, dest_out, stream)
+        self._pending_rounds = max_rounds
+        self._check(self.lib.mgs_pack_streams_device_async(*args))
+
+    def streams_result(self):
+        nxt, so, lrec, lbytes = self._rounds_buffers(self._pending_rounds)
+        base = np.zeros(self._pending_rounds * self.nranks, dtype=np.int64)
+        r = capi.Rounds()
+        self._check(self.lib.mgs_pack_streams_result(
+            self.h, C.byref(r), nxt.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p),
+            base.ctypes.data_as(C.c_void_p), lrec.ctypes.data_as(C.c_void_p), lbytes.ctypes.data_as(C.c_void_p)))
+        return RoundsResult(r, nxt, so, lrec, lbytes, self.nranks, base)
 
     def pack_noalloc(self, records, n_end, send_image, start=0, rec_off=None,
                      init_offset=None, local_out=None, dest_out=None, stream=None):
