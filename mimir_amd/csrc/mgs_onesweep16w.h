@@ -505,7 +505,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
         // streams layout: this workgroup finds the rounds instead of sweeping
         static_assert(sizeof(FinderLds) <= sizeof(srec), "the finder's tables live in the tile image");
         FinderSrc16 src{p};
-        os_round_finder(p, P, src, reinterpret_cast<FinderLds *>(srec), tid, THREADS);
+        os_round_finder<FinderSrc16, THREADS / 64, TILE / 64>(p, P, src, reinterpret_cast<FinderLds *>(srec), tid);
         return;
     }
 

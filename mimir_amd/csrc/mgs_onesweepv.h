@@ -208,15 +208,26 @@ struct FinderSrcV {
             reinterpret_cast<uint4 *>(sin)[ch] = reinterpret_cast<const uint4 *>(a0)[ch];
         __syncthreads();
     }
-    __device__ void info(uint32_t tile, uint32_t i, uint32_t &d, uint32_t &u, bool &valid) const
+    struct Pre {
+        uint64_t o0, o1;
+    };
+    __device__ Pre fetch(uint32_t tile, uint32_t i, bool &valid) const
     {
         const uint64_t T = q.os.tile_records;
         const uint64_t idx = (uint64_t) tile * T + i;
         valid = i < T && idx < q.n;
+        Pre f = {0, 0};
+        if (valid) {
+            f.o0 = ov_offset(q, idx);
+            f.o1 = ov_offset(q, idx + 1);
+        }
+        return f;
+    }
+    __device__ void info(const Pre &f, uint32_t &d, uint32_t &u, bool &valid) const
+    {
         d = 0;
         u = 0;
-        if (!valid) return;
-        const uint64_t o0 = ov_offset(q, idx), o1 = ov_offset(q, idx + 1);
+        const uint64_t o0 = f.o0, o1 = f.o1;
         const uint32_t len = (uint32_t) (o1 - o0);
         uint32_t klen = 0;
         const uint64_t r = o0 - s + shift;
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
         // streams layout: this workgroup finds the rounds instead of sweeping
         static_assert(sizeof(FinderLds) <= sizeof(sout), "the finder's tables live in the image buffer");
         FinderSrcV src{q, sin};
-        os_round_finder(p, P, src, reinterpret_cast<FinderLds *>(sout), tid, THREADS);
+        os_round_finder<FinderSrcV, THREADS / 64, T / 64>(p, P, src, reinterpret_cast<FinderLds *>(sout), tid);
         return;
     }
 

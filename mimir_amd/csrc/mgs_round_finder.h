@@ -44,27 +44,32 @@ struct FinderLds {
 };
 
 // 16-byte records straight from global memory.
+// A source hands out a record in two steps, so that a wave can have the loads of all its
+// rows in flight before it looks at any of them: fetch (loads only), then info.
 struct FinderSrc16 {
     const OsParams &p;
+    typedef uint4 Pre;
     __device__ void stage(uint32_t, int, int) {}
-    __device__ void info(uint32_t tile, uint32_t i, uint32_t &d, uint32_t &u, bool &valid) const
+    __device__ Pre fetch(uint32_t tile, uint32_t i, bool &valid) const
     {
         const uint64_t idx = (uint64_t) tile * p.tile_records + i;
         valid = i < p.tile_records && idx < p.n;
-        d = 0;
+        return valid ? p.rec[idx] : make_uint4(0, 0, 0, 0);
+    }
+    __device__ void info(const Pre &r, uint32_t &d, uint32_t &u, bool &valid) const
+    {
+        d = valid ? fastmod(hash_rec16(r.x, r.y, r.z, r.w, p.klen), p.fm) : 0u;
         u = 1;
-        if (valid) {
-            const uint4 r = p.rec[idx];
-            d = fastmod(hash_rec16(r.x, r.y, r.z, r.w, p.klen), p.fm);
-        }
     }
 };
 
-template <class Src>
-__device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, Src &src, FinderLds *x, int tid,
-                                             int nthreads)
+// NW waves in the workgroup, tiles of at most MAXROWS rows of 64 records.
+template <class Src, int NW, int MAXROWS>
+__device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, Src &src, FinderLds *x, int tid)
 {
-    const int lane = tid & 63, w = tid >> 6, nw = nthreads >> 6;
+    constexpr int nw = NW, nthreads = NW * 64, RPW = (MAXROWS + NW - 1) / NW;
+    static_assert(MAXROWS <= FR_MAX_ROWS, "the finder's tables hold FR_MAX_ROWS rows");
+    const int lane = tid & 63, w = tid >> 6;
     const uint32_t PC = p.P; // columns of the chained scan: P destinations (+ the local record count)
     const uint32_t rows = (p.tile_records + 63u) / 64u;
     const bool extra_col = PC > P; // column P counts the records of the local rank
@@ -177,18 +182,31 @@ __device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, S
 
         // ---- every wave: destinations and units of the tile's records, units per (row, column)
         src.stage(tile, tid, nthreads);
-        for (uint32_t r = (uint32_t) w; r < rows; r += (uint32_t) nw) {
-            x->rowcnt[r][lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t i = r * 64u + (uint32_t) lane;
-            uint32_t d, u;
-            bool valid;
-            src.info(tile, i, d, u, valid);
-            x->dest[i] = valid ? (uint8_t) d : (uint8_t) 0xFF;
-            x->units[i] = valid ? u : 0u;
-            if (valid) {
-                atomicAdd(&x->rowcnt[r][d], u);
-                if (extra_col && (int32_t) d == p.self) atomicAdd(&x->rowcnt[r][P], 1u);
+        {
+            typename Src::Pre pre[RPW];
+            bool pv[RPW];
+#pragma unroll
+            for (int kk = 0; kk < RPW; kk++) {
+                const uint32_t r = (uint32_t) w + (uint32_t) kk * nw;
+                pv[kk] = false;
+                if (r < rows) pre[kk] = src.fetch(tile, r * 64u + (uint32_t) lane, pv[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < RPW; kk++) {
+                const uint32_t r = (uint32_t) w + (uint32_t) kk * nw;
+                if (r >= rows) continue;
+                x->rowcnt[r][lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t i = r * 64u + (uint32_t) lane;
+                uint32_t d = 0, u = 0;
+                bool valid = pv[kk];
+                if (valid) src.info(pre[kk], d, u, valid);
+                x->dest[i] = valid ? (uint8_t) d : (uint8_t) 0xFF;
+                x->units[i] = valid ? u : 0u;
+                if (valid) {
+                    atomicAdd(&x->rowcnt[r][d], u);
+                    if (extra_col && (int32_t) d == p.self) atomicAdd(&x->rowcnt[r][P], 1u);
+                }
             }
         }
         __syncthreads();
@@ -198,6 +216,7 @@ __device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, S
         // ---- wave 0: every cut of the tile, in emit order
         if (w == 0) {
             unsigned long long tot = 0;
+#pragma unroll 8
             for (uint32_t r = 0; r < rows; r++) tot += x->rowcnt[r][lane];
             unsigned long long run = hi_val - tot; // lane = column: units before the tile
             uint32_t r0 = 0;
@@ -205,13 +224,16 @@ __device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, S
                 // the first row at whose end a partition is past its limit
                 uint32_t rs = rows;
                 unsigned long long acc = run;
-                for (uint32_t r = r0; r < rows; r++) {
-                    const unsigned long long cn = x->rowcnt[r][lane];
-                    if (__ballot(is_part && acc + cn > lim)) {
-                        rs = r;
-                        break;
+                for (uint32_t r = r0; r < rows && rs == rows; r += 8) { // eight rows' counts in flight at a time
+                    uint32_t cn[8];
+#pragma unroll
+                    for (uint32_t jj = 0; jj < 8; jj++) cn[jj] = (r + jj < rows) ? x->rowcnt[r + jj][lane] : 0u;
+#pragma unroll
+                    for (uint32_t jj = 0; jj < 8; jj++) {
+                        if (rs != rows || r + jj >= rows) continue;
+                        if (__ballot(is_part && acc + cn[jj] > lim)) rs = r + jj;
+                        else acc += cn[jj];
                     }
-                    acc += cn;
                 }
                 if (rs == rows) break; // no (further) cut in this tile
                 run = acc;
