@@ -187,6 +187,11 @@ def main():
                          "rounds are views into it (mgs_pack_streams_device: the sweep never waits for a round "
                          "cut); images: one send image per round (mgs_pack_rounds_device).  Same rounds, same "
                          "bytes per partition either way.")
+    ap.add_argument("--exchange", default="batch", choices=["batch", "rounds"],
+                    help="N > 1, streams layout: batch = everything a destination gets from this rank in the "
+                         "whole batch as ONE message (its rounds lie back to back in the stream; the rounds come "
+                         "out as views on the receive side too); rounds = one grouped send/recv batch per "
+                         "round of the reference.  The image layout always exchanges round by round.")
     args = ap.parse_args()
     if args.workload != "u64" and args.records == 1e9:
         args.records = 5e7
@@ -275,8 +280,11 @@ def main():
     if distributed:
         local = torch.empty(int(total_bytes * hot_share) + total_bytes // 64 + 65536, dtype=torch.uint8,
                             device=f"cuda:{dev}")
-        recv = torch.empty(max_rounds * stride, dtype=torch.uint8, device=f"cuda:{dev}")
-        from mimir_amd.exchange import exchange_rounds
+        batch_exchange = streams_layout and args.exchange == "batch"
+        # batch: one receive stream per source; else one receive image per round
+        recv = torch.empty(P * stream_cap if batch_exchange else max_rounds * stride, dtype=torch.uint8,
+                           device=f"cuda:{dev}")
+        from mimir_amd.exchange import exchange_rounds, exchange_streams
 
     kernel_ms, pack_s, stats = [], [], {"sent_max": 0, "rounds": 0, "exchanges": 0}
 
@@ -294,12 +302,14 @@ def main():
         if distributed:
             so = r.round_send_offset
             part, bases = (stream_cap, r.round_base) if streams_layout else (buf_size, None)
-            if backend == "gloo":   # rehearsal: through host memory
-                host_recv = torch.empty(recv.shape, dtype=torch.uint8)
-                rc, R = exchange_rounds(images.cpu(), stride, so, part, host_recv, stride, round_base=bases)
-                recv.copy_(host_recv)
+            src_img = images.cpu() if backend == "gloo" else images   # gloo rehearsal: through host memory
+            dst_img = torch.empty(recv.shape, dtype=torch.uint8) if backend == "gloo" else recv
+            if batch_exchange:
+                rc, _, R = exchange_streams(src_img, stream_cap, so, bases, dst_img, stream_cap)
             else:
-                rc, R = exchange_rounds(images, stride, so, part, recv, stride, round_base=bases)
+                rc, R = exchange_rounds(src_img, stride, so, part, dst_img, stride, round_base=bases)
+            if backend == "gloo":
+                recv.copy_(dst_img)
             stats["exchanges"] = R
             stats["sent_max"] = max(stats["sent_max"], int(so.sum(axis=0).max()))
         return r
@@ -374,7 +384,10 @@ def main():
         out["pack_only_records_per_s"] = pack_only
         xfer_s = dt / args.steps - sum(pack_s) / len(pack_s)
         hot = stats["sent_max"]   # bytes of the busiest (this rank -> peer) pair over the whole step
-        out["exchange"] = {"exchanges": stats["exchanges"], "hottest_pair_bytes": hot,
+        out["exchange"] = {"exchanges": stats["exchanges"],
+                           "messages": ("one per (source, destination) pair for the whole batch; the rounds are views "
+                                        "on both sides" if batch_exchange else "one grouped send/recv batch per round"),
+                           "hottest_pair_bytes": hot,
                            "exchange_ms": xfer_s * 1e3,
                            "xgmi_floor_ms": hot / (XGMI_LINK_GBS * 1e9) * 1e3,
                            "frac_of_xgmi_pair_roofline": (hot / (XGMI_LINK_GBS * 1e9)) / max(xfer_s, 1e-9)}

@@ -532,6 +532,37 @@ int mgs_stager_send_image_host(mgs_stager *s, const void **host_image,
 int mgs_stager_send_image_device(mgs_stager *s, void **d_image,
                                  const int64_t **send_offset);
 int mgs_stager_round_done(mgs_stager *s);
+/* mgs_stager_put inlined by the caller (the per-record write() of a shim costs a
+ * call into the library otherwise): the staging buffer itself.  The caller
+ * appends wire-form records at bytes + used, stores each record's end in
+ * off[nrec + 1] (a fixed-width layout too), stops at cap bytes / max_rec
+ * records, and hands the new fill back with mgs_stager_commit before any other
+ * stager call.  writable == 0: use mgs_stager_put (the buffer's contents are in
+ * the pack kernels' hands, or the stager is combining). */
+typedef struct mgs_stage_window {
+    uint8_t *bytes;
+    uint32_t *off;
+    int64_t cap;
+    uint64_t max_rec;
+    int64_t used;
+    uint64_t nrec;
+    int32_t writable;
+    int32_t reserved;
+} mgs_stage_window;
+int mgs_stager_window(mgs_stager *s, mgs_stage_window *w);
+int mgs_stager_commit(mgs_stager *s, int64_t used, uint64_t nrec);
+/* For a transport that moves device memory (RCCL, GPU-aware MPI, peer copies):
+ * the device receive image -- nranks*buf_size bytes, the reference's recv_buffer
+ * (src/collectiveshuffler.h:97-98), to be filled source by source without gaps
+ * (:637-639) -- and save_data (:563-585) on its first nbytes bytes: the record
+ * boundaries are found on the GPU (mgs_unpack_device), bytes and offsets are
+ * copied to pinned host memory for out->write.  *host_rec_off is NULL for
+ * layouts mgs_unpack_device does not take (walk the bytes then). */
+int mgs_stager_recv_image_device(mgs_stager *s, void **d_recv);
+int mgs_stager_recv_to_host(mgs_stager *s, int64_t nbytes,
+                            const void **host_records,
+                            const uint32_t **host_rec_off,
+                            uint64_t *n_records);
 int mgs_stager_set_combine(mgs_stager *s, int op);
 
 /* Device time of the dominant kernel of the last completed pack call (the

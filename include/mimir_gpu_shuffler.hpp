@@ -61,6 +61,18 @@ class Exchange {
     virtual void alltoall_int(const int *send, int *recv) = 0;
     virtual void alltoallv_bytes(const char *sendbuf, const int *scount, const int *sdispl,
                                  char *recvbuf, const int *rcount, const int *rdispl) = 0;
+    // The payload exchange on DEVICE memory (RCCL grouped send/recv, GPU-aware MPI, peer
+    // copies over xGMI): same arguments as alltoallv_bytes, both buffers device pointers,
+    // displacements 64-bit.  Blocking like MPI_Alltoallv: on return the receive image is
+    // complete and the send image may be overwritten.  Returns false -- having moved nothing
+    // -- when the transport cannot move device memory (the default); the answer must be the
+    // same on every rank.  The shuffler then exchanges through host memory.
+    virtual bool alltoallv_device(const void *d_sendbuf, const int *scount, const int64_t *sdispl,
+                                  void *d_recvbuf, const int *rcount, const int64_t *rdispl)
+    {
+        (void) d_sendbuf; (void) scount; (void) sdispl; (void) d_recvbuf; (void) rcount; (void) rdispl;
+        return false;
+    }
     // Non-blocking forms for NBGpuShuffler (MPI_Ialltoall / MPI_Ialltoallv /
     // MPI_Test / MPI_Wait; the counts and the payloads travel on two separate
     // communicators in the reference, src/nbcollectiveshuffler.h:68-69).  A
@@ -100,6 +112,8 @@ struct wire {
         out = reinterpret_cast<T *>(buf);
         return (int) sizeof(T) * count;
     }
+    // the typed pointer of an object known to start at buf (nothing is measured)
+    static void at(char *buf, T *&out, std::vector<T> &) { out = reinterpret_cast<T *>(buf); }
 };
 
 template <typename T>
@@ -127,6 +141,12 @@ struct wire<T, typename std::enable_if<std::is_same<T, char *>::value
         }
         out = ptrs.data();
         return n;
+    }
+    // one string known to start at buf (nothing is measured)
+    static void at(char *buf, T *&out, std::vector<T> &ptrs) {
+        ptrs.resize(1);
+        ptrs[0] = buf;
+        out = ptrs.data();
     }
 };
 
@@ -179,6 +199,7 @@ class GpuShuffler : public Writable<KeyType, ValType> {
         if (tlb != 0) fail("GpuShuffler: MIMIR_COMM_SIZE above 1 GiB is not supported\n");
         handle = NULL;
         stager = NULL;
+        memset(&win, 0, sizeof(win));
         shuffle_times = 0;
         done_flag = done_count = 0;
         kvcount = 0;
@@ -214,24 +235,42 @@ class GpuShuffler : public Writable<KeyType, ValType> {
         recv_buffer.resize((size_t) buf_size * (size_t) shuffle_size);
         send_count.assign((size_t) shuffle_size, 0);
         recv_count.assign((size_t) shuffle_size, 0);
+        d_s_displs.assign((size_t) shuffle_size, 0);
+        d_r_displs.assign((size_t) shuffle_size, 0);
+        send_bytes = recv_bytes = 0;
+        device_exchanges = 0;
         a2a_s_displs.assign((size_t) shuffle_size, 0);
         a2a_r_displs.assign((size_t) shuffle_size, 0);
         done_flag = done_count = 0;
+        sync_window();
         return true;
     }
 
+    // kv_to_bytes into the staging buffer (src/collectiveshuffler.h:143-146): the two copies
+    // are made right here, in the staging window the stager handed out; the library is only
+    // called when the window is full.
     virtual int write(KeyType *key, ValType *val)
     {
         const int klen = wire<KeyType>::size(key, keycount);
         const int vlen = wire<ValType>::size(val, valcount);
         const char *kb = wire<KeyType>::bytes(key, keycount, key_scratch);
         const char *vb = wire<ValType>::bytes(val, valcount, val_scratch);
+        const int64_t len = (int64_t) klen + vlen;
+        if (win.writable && len > 0 && win.nrec < win.max_rec && win.used + len <= win.cap) {
+            memcpy(win.bytes + win.used, kb, (size_t) klen);
+            if (vlen) memcpy(win.bytes + win.used + klen, vb, (size_t) vlen);
+            win.used += len;
+            win.off[++win.nrec] = (uint32_t) win.used;
+            return true;
+        }
+        commit_window();
         int rc = mgs_stager_put(stager, kb, (uint32_t) klen, vb, (uint32_t) vlen);
         if (rc == 1) {
             drain();
             rc = mgs_stager_put(stager, kb, (uint32_t) klen, vb, (uint32_t) vlen);
         }
         if (rc != MGS_OK) fail(mgs_stager_last_error(stager));
+        sync_window();
         return true;
     }
 
@@ -253,12 +292,31 @@ class GpuShuffler : public Writable<KeyType, ValType> {
     virtual uint64_t get_record_count() { return kvcount; } // src/baseshuffler.h:265
 
     int get_shuffle_times() const { return shuffle_times; }
+    // What the reference's profiler counts in exchange_kv (src/stat.h:51-91, COUNTER_SEND_BYTES /
+    // COUNTER_RECV_BYTES / COUNTER_SHUFFLE_TIMES; src/collectiveshuffler.h:593,652,661): payload
+    // bytes handed to / received from the all-to-all-v, and the exchanges that moved data.
+    uint64_t get_send_bytes() const { return send_bytes; }
+    uint64_t get_recv_bytes() const { return recv_bytes; }
+    // exchanges whose payload travelled between device images (Exchange::alltoallv_device)
+    int get_device_exchanges() const { return device_exchanges; }
 
   protected:
     // Pack everything staged; a full partition ends the round
     // (src/collectiveshuffler.h:148-160).
+    void commit_window()
+    {
+        if (win.writable && mgs_stager_commit(stager, win.used, win.nrec) != MGS_OK)
+            fail(mgs_stager_last_error(stager));
+        win.writable = 0;
+    }
+    void sync_window()
+    {
+        if (mgs_stager_window(stager, &win) != MGS_OK) fail(mgs_stager_last_error(stager));
+    }
+
     void drain()
     {
+        commit_window();
         for (;;) {
             mgs_round r;
             const void *local = NULL;
@@ -273,6 +331,7 @@ class GpuShuffler : public Writable<KeyType, ValType> {
             if (drained) break;
             exchange_kv();
         }
+        sync_window();
     }
 
     // Called before the records of one source rank are handed to `out` (the own
@@ -284,9 +343,9 @@ class GpuShuffler : public Writable<KeyType, ValType> {
     // src/collectiveshuffler.h:587-674
     virtual void exchange_kv()
     {
-        const void *image = NULL;
+        void *d_image = NULL;
         const int64_t *send_offset = NULL;
-        if (mgs_stager_send_image_host(stager, &image, &send_offset) != MGS_OK)
+        if (mgs_stager_send_image_device(stager, &d_image, &send_offset) != MGS_OK)
             fail(mgs_stager_last_error(stager));
         for (int i = 0; i < shuffle_size; i++) send_count[(size_t) i] = done_flag ? -1 : (int) send_offset[i];
         comm->alltoall_int(send_count.data(), recv_count.data());
@@ -303,14 +362,51 @@ class GpuShuffler : public Writable<KeyType, ValType> {
         for (int i = 0; i < shuffle_size; i++) {
             a2a_s_displs[(size_t) i] = (int) (i * buf_size);
             a2a_r_displs[(size_t) i] = (int) recvcount;
+            d_s_displs[(size_t) i] = (int64_t) i * buf_size;
+            d_r_displs[(size_t) i] = recvcount;
             recvcount += recv_count[(size_t) i];
+            send_bytes += (uint64_t) send_count[(size_t) i];
         }
-        comm->alltoallv_bytes(static_cast<const char *>(image), send_count.data(), a2a_s_displs.data(),
-                              recv_buffer.data(), recv_count.data(), a2a_r_displs.data());
-        for (int i = 0; i < shuffle_size; i++) { // save_data, :563-585
-            if (recv_count[(size_t) i] > 0) {
+        recv_bytes += (uint64_t) recvcount;
+        // the payload: between the device images when the transport can, else through host memory
+        void *d_recv = NULL;
+        if (mgs_stager_recv_image_device(stager, &d_recv) != MGS_OK) fail(mgs_stager_last_error(stager));
+        if (comm->alltoallv_device(d_image, send_count.data(), d_s_displs.data(), d_recv, recv_count.data(),
+                                   d_r_displs.data())) {
+            device_exchanges += 1;
+            const void *host = NULL;
+            const uint32_t *off = NULL;
+            uint64_t nrec = 0;
+            if (mgs_stager_recv_to_host(stager, recvcount, &host, &off, &nrec) != MGS_OK)
+                fail(mgs_stager_last_error(stager));
+            char *bytes = const_cast<char *>(static_cast<const char *>(host));
+            uint64_t rec = 0;
+            for (int i = 0; i < shuffle_size; i++) { // save_data, :563-585
+                if (recv_count[(size_t) i] <= 0) continue;
                 begin_source(i);
-                deliver(recv_buffer.data() + a2a_r_displs[(size_t) i], recv_count[(size_t) i]);
+                const int64_t end = d_r_displs[(size_t) i] + recv_count[(size_t) i];
+                if (off == NULL) {
+                    deliver(bytes + d_r_displs[(size_t) i], recv_count[(size_t) i]);
+                    continue;
+                }
+                // the record boundaries came from the device: no length is measured here
+                while (rec < nrec && (int64_t) off[rec] < end) {
+                    deliver_one(bytes + off[rec], (int) (off[rec + 1] - off[rec]));
+                    rec++;
+                }
+            }
+        }
+        else {
+            const void *image = NULL;
+            if (mgs_stager_send_image_host(stager, &image, &send_offset) != MGS_OK)
+                fail(mgs_stager_last_error(stager));
+            comm->alltoallv_bytes(static_cast<const char *>(image), send_count.data(), a2a_s_displs.data(),
+                                  recv_buffer.data(), recv_count.data(), a2a_r_displs.data());
+            for (int i = 0; i < shuffle_size; i++) { // save_data, :563-585
+                if (recv_count[(size_t) i] > 0) {
+                    begin_source(i);
+                    deliver(recv_buffer.data() + a2a_r_displs[(size_t) i], recv_count[(size_t) i]);
+                }
             }
         }
         mgs_stager_round_done(stager);
@@ -351,6 +447,20 @@ class GpuShuffler : public Writable<KeyType, ValType> {
             out->write(key, val);
         }
     }
+
+    // One record whose extent is known (layouts mgs_unpack_device parses: one key object, a
+    // fixed-width or absent value): the key starts the record, the value ends it.
+    void deliver_one(char *rec, int len)
+    {
+        KeyType *key = NULL;
+        ValType *val = NULL;
+        const int vlen = wire<ValType>::is_void ? 0 : wire<ValType>::size(NULL, valcount);
+        wire<KeyType>::at(rec, key, key_ptrs);
+        val_at(rec + len - vlen, val, std::integral_constant<bool, wire<ValType>::is_void>());
+        out->write(key, val);
+    }
+    void val_at(char *, ValType *&val, std::true_type) { val = NULL; }
+    void val_at(char *buf, ValType *&val, std::false_type) { wire<ValType>::at(buf, val, val_ptrs); }
 
     int val_from(char *, ValType *&val, std::true_type)
     {
@@ -402,8 +512,12 @@ class GpuShuffler : public Writable<KeyType, ValType> {
     int64_t comm_buf_size, buf_size;
     mgs_handle *handle;
     mgs_stager *stager;
+    mgs_stage_window win; // the staging buffer, for the inlined put in write()
     std::vector<char> recv_buffer, key_scratch, val_scratch;
     std::vector<int> send_count, recv_count, a2a_s_displs, a2a_r_displs;
+    std::vector<int64_t> d_s_displs, d_r_displs;
+    uint64_t send_bytes, recv_bytes;
+    int device_exchanges;
     typename ptr_store<KeyType>::type key_ptrs;
     typename ptr_store<ValType>::type val_ptrs;
 };
@@ -583,7 +697,9 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
                         m->s_displs[(size_t) i] = (int) (i * this->buf_size);
                         m->r_displs[(size_t) i] = (int) recvcount;
                         recvcount += m->recv_count[(size_t) i];
+                        this->send_bytes += (uint64_t) m->send_offset[(size_t) i];
                     }
+                    this->recv_bytes += (uint64_t) recvcount;
                     m->a2av_req = this->comm->ialltoallv_bytes(m->send_buffer.data(), m->send_offset.data(),
                                                                m->s_displs.data(), m->recv_buffer.data(),
                                                                m->recv_count.data(), m->r_displs.data());

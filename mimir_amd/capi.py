@@ -123,6 +123,11 @@ SYMBOLS = {
     "mgs_stager_send_image_device": (C.c_int, [_VP, C.POINTER(_VP),
                                                C.POINTER(C.POINTER(C.c_int64))]),
     "mgs_stager_round_done": (C.c_int, [_VP]),
+    "mgs_stager_window": (C.c_int, [_VP, _VP]),
+    "mgs_stager_commit": (C.c_int, [_VP, C.c_int64, C.c_uint64]),
+    "mgs_stager_recv_image_device": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "mgs_stager_recv_to_host": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP), C.POINTER(C.POINTER(C.c_uint32)),
+                                          C.POINTER(C.c_uint64)]),
     "mgs_stager_set_combine": (C.c_int, [_VP, C.c_int]),
     "mgs_synth_u64_records": (C.c_int, [_VP, C.c_uint64, C.c_uint64,
                                         C.c_uint64, C.c_int, _VP]),

@@ -31,6 +31,12 @@ struct mgs_stager {
     uint8_t *d_local = nullptr; // local-bypass records of one pack call
     uint8_t *h_image = nullptr; // pinned mirror of the send image (host exchange)
     uint8_t *h_local = nullptr; // pinned
+    // receive side of an exchange that moves device memory (made on first use)
+    uint8_t *d_recv = nullptr;  // nranks * buf_size: source 0's bytes, then source 1's, ...
+    uint8_t *h_recv = nullptr;  // pinned mirror
+    uint32_t *d_roff = nullptr; // record offsets found by mgs_unpack_device
+    uint32_t *h_roff = nullptr; // pinned mirror
+    uint64_t roff_cap = 0;
     int64_t used = 0;
     uint64_t nrec = 0;
     uint64_t cursor = 0; // first staged record not packed yet
@@ -222,6 +228,10 @@ void mgs_stager_destroy(mgs_stager *s)
     if (s->d_off) (void) hipFree(s->d_off);
     if (s->d_image) (void) hipFree(s->d_image);
     if (s->d_local) (void) hipFree(s->d_local);
+    if (s->d_recv) (void) hipFree(s->d_recv);
+    if (s->d_roff) (void) hipFree(s->d_roff);
+    if (s->h_recv) (void) hipHostFree(s->h_recv);
+    if (s->h_roff) (void) hipHostFree(s->h_roff);
     if (s->stream) (void) hipStreamDestroy(s->stream);
     if (prev >= 0) (void) hipSetDevice(prev);
     delete s;
@@ -296,6 +306,37 @@ int mgs_stager_put(mgs_stager *s, const void *key, uint32_t klen, const void *va
 }
 
 uint64_t mgs_stager_pending(const mgs_stager *s) { return s ? s->nrec - s->cursor : 0; }
+
+// The staging buffer itself, for a caller that inlines mgs_stager_put: it appends records at
+// bytes + used, stores the new end in off[nrec + 1] and hands the new fill back with
+// mgs_stager_commit before any other stager call.  writable == 0: the buffer cannot take
+// records right now (its contents are on their way through the pack kernels, or the stager
+// combines and manages the buffer itself): use mgs_stager_put.
+int mgs_stager_window(mgs_stager *s, mgs_stage_window *w)
+{
+    if (!s || !w) return MGS_ERR_ARG;
+    w->bytes = s->h_stage;
+    w->off = s->h_off;
+    w->cap = s->cap;
+    w->max_rec = s->max_rec;
+    w->used = s->used;
+    w->nrec = s->nrec;
+    w->writable = (!s->uploaded && s->combine_op < 0) ? 1 : 0;
+    return MGS_OK;
+}
+
+int mgs_stager_commit(mgs_stager *s, int64_t used, uint64_t nrec)
+{
+    if (!s) return MGS_ERR_ARG;
+    if (s->uploaded || s->combine_op >= 0 || used < s->used || nrec < s->nrec || used > s->cap || nrec > s->max_rec
+        || (int64_t) s->h_off[nrec] != used) {
+        s->err = "mgs_stager_commit: the fill does not continue the window handed out";
+        return MGS_ERR_STATE;
+    }
+    s->used = used;
+    s->nrec = nrec;
+    return MGS_OK;
+}
 
 // Pack the staged records that are not packed yet into the current round.
 // *drained = 1: every staged record was consumed and the staging buffer is
@@ -404,6 +445,83 @@ int mgs_stager_send_image_device(mgs_stager *s, void **d_image, const int64_t **
     if (!s || !d_image || !send_offset) return MGS_ERR_ARG;
     *d_image = s->d_image;
     *send_offset = s->send_offset;
+    return MGS_OK;
+}
+
+// The receive image of an exchange that writes device memory (RCCL, GPU-aware MPI,
+// peer copies): nranks * buf_size bytes, the reference's recv_buffer
+// (src/collectiveshuffler.h:97-98), filled source by source without gaps (:637-639).
+int mgs_stager_recv_image_device(mgs_stager *s, void **d_recv)
+{
+    if (!s || !d_recv) return MGS_ERR_ARG;
+    if (!s->d_recv) {
+        int prev = -1;
+        (void) hipGetDevice(&prev);
+        const size_t image = (size_t) s->desc.nranks * (size_t) s->desc.buf_size;
+        // shortest record of the layout: the offsets table holds one entry per record
+        const mgs_layout &l = s->desc.layout;
+        const int fl = fixed_len(l);
+        const size_t minlen = fl > 0 ? (size_t) fl : 1 + (l.val_kind == MGS_VAL_FIXED ? (size_t) l.val_bytes : 0);
+        s->roff_cap = image / minlen + 2;
+        hipError_t e = hipSetDevice(s->desc.device);
+        if (e == hipSuccess) e = hipMalloc(&s->d_recv, image);
+        if (e == hipSuccess) e = hipMalloc(&s->d_roff, s->roff_cap * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipHostMalloc(&s->h_recv, image, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(&s->h_roff, s->roff_cap * sizeof(uint32_t), hipHostMallocDefault);
+        if (prev >= 0) (void) hipSetDevice(prev);
+        if (e != hipSuccess) {
+            s->err = sfmt("mgs_stager_recv_image_device: %s", hipGetErrorString(e));
+            return MGS_ERR_HIP;
+        }
+    }
+    *d_recv = s->d_recv;
+    return MGS_OK;
+}
+
+// save_data (src/collectiveshuffler.h:563-585) for a receive image that lies in device
+// memory: the record boundaries of its first nbytes bytes are found on the GPU
+// (mgs_unpack_device) and the bytes and the offsets are copied to pinned host memory, where
+// `out->write` needs them.  *host_rec_off: n_records + 1 offsets into *host_records, or
+// NULL for a layout the device parse does not take (the caller walks the bytes then).
+int mgs_stager_recv_to_host(mgs_stager *s, int64_t nbytes, const void **host_records,
+                            const uint32_t **host_rec_off, uint64_t *n_records)
+{
+    if (!s || !host_records || !host_rec_off || !n_records || nbytes < 0 || !s->d_recv
+        || nbytes > (int64_t) s->desc.nranks * s->desc.buf_size) {
+        if (s) s->err = "mgs_stager_recv_to_host: bad argument (or no receive image yet)";
+        return MGS_ERR_ARG;
+    }
+    *host_records = s->h_recv;
+    *host_rec_off = nullptr;
+    *n_records = 0;
+    if (nbytes == 0) return MGS_OK;
+    const mgs_layout &l = s->desc.layout;
+    const bool device_parse = fixed_len(l) > 0
+                              || (l.key_kind == MGS_KEY_CSTR && l.key_count <= 1
+                                  && (l.val_kind == MGS_VAL_VOID || (l.val_kind == MGS_VAL_FIXED && l.val_bytes <= 62)));
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    struct Restore {
+        int p;
+        ~Restore() { if (p >= 0) (void) hipSetDevice(p); }
+    } restore{prev};
+    STG_HIP(s, hipSetDevice(s->desc.device));
+    STG_HIP(s, hipMemcpyAsync(s->h_recv, s->d_recv, (size_t) nbytes, hipMemcpyDeviceToHost, s->stream));
+    if (device_parse) {
+        uint64_t n = 0;
+        int ncuts = 0;
+        mgs_page_cut cut;
+        const int rc = mgs_unpack_device(s->h, s->d_recv, (uint64_t) nbytes, s->d_roff, s->roff_cap, (int64_t) 1 << 40, 0,
+                                         &n, &cut, 1, &ncuts, s->stream);
+        if (rc != MGS_OK) {
+            s->err = mgs_last_error(s->h);
+            return rc;
+        }
+        STG_HIP(s, hipMemcpyAsync(s->h_roff, s->d_roff, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        *n_records = n;
+        *host_rec_off = s->h_roff;
+    }
+    STG_HIP(s, hipStreamSynchronize(s->stream));
     return MGS_OK;
 }
 

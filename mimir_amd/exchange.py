@@ -148,3 +148,62 @@ def exchange_rounds(send_images, image_stride, round_send_offset, buf_size, recv
     if send_images.is_cuda:
         torch.cuda.current_stream(dev).synchronize()
     return recv_count, R
+
+
+def exchange_streams(streams, stream_cap, round_send_offset, round_base, recv_streams, recv_cap, group=None):
+    """All exchanges of a batch packed in the streams layout (DevicePacker.pack_streams) as
+    ONE all-to-all-v.  In that layout the partitions a rank sends to destination d in its
+    rounds 0, 1, 2, ... lie back to back in stream d, so everything d gets from this rank in
+    the whole batch is one contiguous run: it travels as one message per (source,
+    destination) pair -- P-1 sends and P-1 receives per rank instead of that many per round
+    -- into one receive stream per source.  The reference's rounds survive as views: the
+    counts of all rounds are exchanged as in exchange_rounds, and what source s sent in its
+    round k is bytes [recv_base[k, s], + recv_count[k, s]) of receive stream s; walking k, then
+    s, visits the received records in the order save_data hands them to the sink
+    (src/collectiveshuffler.h:563-585, :637-639).
+
+    streams          : uint8; stream d at [d*stream_cap :]
+    round_send_offset: host int64 [R_mine, P]; round_base: host int64 [R_mine, P]
+    recv_streams     : uint8; receive stream s at [s*recv_cap :]
+    Returns (recv_count int64 [R, P], recv_base int64 [R, P], R)."""
+    import numpy as np
+    P = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    dev = streams.device
+    so = np.asarray(round_send_offset, dtype=np.int64).reshape(-1, P)
+    base = np.asarray(round_base, dtype=np.int64).reshape(-1, P)
+    r_mine = so.shape[0]
+    rmax = torch.tensor([r_mine], dtype=torch.int64, device=dev)
+    dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group)
+    R = int(rmax.item())
+    full = np.zeros((R, P), dtype=np.int64)
+    full[:r_mine] = so
+    send = torch.from_numpy(np.ascontiguousarray(full.T)).to(dev)     # [P, R]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_count = recv.cpu().numpy().T.copy()                         # [R, P]
+    recv_base = np.cumsum(recv_count, axis=0) - recv_count            # where round k of source s begins
+    ops = []
+    for peer in range(P):
+        if peer == me:
+            continue
+        g = dist.get_global_rank(group, peer) if group else peer
+        rc = int(recv_count[:, peer].sum())
+        if rc > recv_cap:
+            raise ValueError(f"receive stream of source {peer} needs {rc} bytes, has {recv_cap}")
+        if rc > 0:
+            ops.append(dist.P2POp(dist.irecv, recv_streams[peer * recv_cap:peer * recv_cap + rc], g, group=group))
+    for peer in range(P):
+        if peer == me:
+            continue
+        g = dist.get_global_rank(group, peer) if group else peer
+        sb = int(full[:, peer].sum())
+        if sb > 0:
+            o = peer * stream_cap + int(base[0][peer])
+            ops.append(dist.P2POp(dist.isend, streams[o:o + sb], g, group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if streams.is_cuda:
+            torch.cuda.current_stream(dev).synchronize()
+    return recv_count, recv_base, R

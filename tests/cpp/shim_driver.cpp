@@ -6,7 +6,14 @@
 //   shim_driver <kind> <P> <comm_bytes> <stage_bytes> <indir> <outdir> [keycount] [nb]
 //   kind: u64 | words | oct | join;  nb: NBGpuShuffler over non-blocking exchanges;
 //   sum (in place of nb): GpuShuffler as the combiner shuffler with MGS_COMBINE_SUM_U64
+// Environment: MGS_SHIM_DEVICE_EXCHANGE=1 -- the transport moves device memory
+// (Exchange::alltoallv_device: copies between the ranks' device images); MGS_SHIM_TIMING=1 --
+// the sinks only count, and rank<r>.counters also holds the wall time of the write() loop.
 #include <pthread.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
 
 #include <map>
 #include <mutex>
@@ -43,6 +50,8 @@ struct Shared {
     std::vector<int> counts;           // P x P
     std::vector<const char *> sendbuf; // per rank
     std::vector<const int *> scount, sdispl;
+    std::vector<const void *> d_send;        // per rank: device send image
+    std::vector<const int64_t *> d_sdispl;
     std::mutex mu;
     std::map<uint64_t, NbOp> a2a, a2av;
 };
@@ -83,6 +92,36 @@ class ThreadExchange : public Exchange {
                    (size_t) rcount[src]);
         }
         pthread_barrier_wait(&s->bar);
+    }
+    // Device memory: every rank pulls its partitions out of the other ranks' device images
+    // (the ranks of this driver share one GPU; between GPUs the same copies are peer copies).
+    bool alltoallv_device(const void *d_sendbuf, const int *scount, const int64_t *sdispl, void *d_recvbuf,
+                          const int *rcount, const int64_t *rdispl)
+    {
+        static const bool on = getenv("MGS_SHIM_DEVICE_EXCHANGE") && atoi(getenv("MGS_SHIM_DEVICE_EXCHANGE")) != 0;
+        if (!on) return false;
+        s->d_send[(size_t) r] = d_sendbuf;
+        s->scount[(size_t) r] = scount;
+        s->d_sdispl[(size_t) r] = sdispl;
+        pthread_barrier_wait(&s->bar);
+        for (int src = 0; src < s->P; src++) {
+            if (rcount[src] != s->scount[(size_t) src][r]) {
+                fprintf(stderr, "count mismatch %d<-%d\n", r, src);
+                std::abort();
+            }
+            if (rcount[src] == 0) continue;
+            const hipError_t e = hipMemcpyAsync(static_cast<char *>(d_recvbuf) + rdispl[src],
+                                                static_cast<const char *>(s->d_send[(size_t) src])
+                                                    + s->d_sdispl[(size_t) src][r],
+                                                (size_t) rcount[src], hipMemcpyDeviceToDevice, NULL);
+            if (e != hipSuccess) {
+                fprintf(stderr, "device exchange copy failed: %s\n", hipGetErrorString(e));
+                std::abort();
+            }
+        }
+        if (hipStreamSynchronize(NULL) != hipSuccess) std::abort();
+        pthread_barrier_wait(&s->bar); // every image has been read: the senders may pack again
+        return true;
     }
     Request ialltoall_int(const int *send, int *recv)
     {
@@ -153,6 +192,11 @@ class DumpSink : public Writable<K, V> {
     uint64_t get_record_count() { return n; }
     int write(K *key, V *val)
     {
+        static const bool count_only = getenv("MGS_SHIM_TIMING") && atoi(getenv("MGS_SHIM_TIMING")) != 0;
+        if (count_only) {
+            n++;
+            return true;
+        }
         std::vector<char> tmp;
         const int kl = wire<K>::size(key, kc);
         const char *kb = wire<K>::bytes(key, kc, tmp);
@@ -220,7 +264,10 @@ static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const s
         c = t;
     }
     c->open();
+    const auto t0 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n; i++) feed(c, blob.data() + off[i], (int) (off[i + 1] - off[i]));
+    const double write_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const uint64_t send_bytes_at_loop_end = c->get_send_bytes();
     c->close();
     std::ofstream(outdir + "/rank" + std::to_string(r) + ".out", std::ios::binary)
         .write(sink.data.data(), (std::streamsize) sink.data.size());
@@ -231,6 +278,11 @@ static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const s
     std::ofstream(outdir + "/rank" + std::to_string(r) + ".txt")
         << c->get_record_count() << " " << c->get_shuffle_times() << " " << (nb ? nb->get_buffer_count() : 1)
         << "\n";
+    // send / recv bytes and exchanges as the reference's profiler counts them; device exchanges;
+    // records written, seconds inside the write() loop, bytes already sent when it ended
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".counters")
+        << c->get_send_bytes() << " " << c->get_recv_bytes() << " " << c->get_device_exchanges() << " " << n << " "
+        << write_s << " " << send_bytes_at_loop_end << "\n";
     delete c;
 }
 
@@ -255,6 +307,8 @@ int main(int argc, char **argv)
     sh.sendbuf.assign((size_t) P, NULL);
     sh.scount.assign((size_t) P, NULL);
     sh.sdispl.assign((size_t) P, NULL);
+    sh.d_send.assign((size_t) P, NULL);
+    sh.d_sdispl.assign((size_t) P, NULL);
     std::vector<std::thread> th;
     for (int r = 0; r < P; r++) {
         th.emplace_back([&, r]() {

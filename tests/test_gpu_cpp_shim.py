@@ -19,10 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "tests", "cpp", "shim_driver")
 
 
+@pytest.mark.parametrize("device_exchange", [False, True])
 @pytest.mark.parametrize("kind,P,keycount", [("u64", 2, 1), ("u64", 4, 1), ("words", 3, 1),
                                              ("oct", 4, 11), ("join", 2, 1)])
-def test_cpp_shim_matches_reference(oracle, kind, P, keycount):
+def test_cpp_shim_matches_reference(oracle, kind, P, keycount, device_exchange):
+    """device_exchange: the transport moves device memory (Exchange::alltoallv_device) -- the
+    partitions travel from send image to receive image on the GPU, the record boundaries of the
+    receive image come from mgs_unpack_device; otherwise through host memory, as with plain MPI."""
     assert os.path.exists(DRIVER), "tests/cpp/shim_driver not built (__graft_entry__.build)"
+    env = dict(os.environ, MGS_SHIM_DEVICE_EXCHANGE="1" if device_exchange else "0")
     counts = [0 if r == 1 else 5000 * (r + 1) + 11 for r in range(P)]
     comm, stage = 16384, 40000
     streams, lay = [], None
@@ -38,7 +43,7 @@ def test_cpp_shim_matches_reference(oracle, kind, P, keycount):
             blob.tofile(os.path.join(ind, f"rank{r}.blob"))
             np.asarray(offs, dtype=np.uint64).tofile(os.path.join(ind, f"rank{r}.off"))
         subprocess.run([DRIVER, kind, str(P), str(comm), str(stage), ind, outd, str(keycount)],
-                       check=True, timeout=240)
+                       check=True, timeout=240, env=env)
         buf_size = capi.geometry(comm, P)[0]
         sinks, stats = refsim.simulate_shuffle(oracle, lay, streams, P, buf_size)
         assert max(s["shuffle_times"] for s in stats) >= 3
@@ -49,6 +54,10 @@ def test_cpp_shim_matches_reference(oracle, kind, P, keycount):
             assert got == sinks[r], f"rank {r}: sink differs"
             kv, times, _ = open(os.path.join(outd, f"rank{r}.txt")).read().split()
             assert int(kv) == stats[r]["kvcount"] and int(times) == stats[r]["shuffle_times"]
+            # COUNTER_SEND_BYTES / COUNTER_RECV_BYTES of the reference's profiler (src/stat.h:51-91)
+            sent, recvd, dev_x = open(os.path.join(outd, f"rank{r}.counters")).read().split()[:3]
+            assert int(sent) == stats[r]["send_bytes"] and int(recvd) == stats[r]["recv_bytes"]
+            assert int(dev_x) == (stats[r]["shuffle_times"] if device_exchange else 0)
 
 
 @pytest.mark.parametrize("kind,P,keycount", [("words", 2, 1), ("u64", 3, 1), ("join", 4, 1), ("oct", 4, 11)])
