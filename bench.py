@@ -187,6 +187,11 @@ def main():
                          "rounds are views into it (mgs_pack_streams_device: the sweep never waits for a round "
                          "cut); images: one send image per round (mgs_pack_rounds_device).  Same rounds, same "
                          "bytes per partition either way.")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="streams layout: a step packs the device-resident batch this many times over, every call "
+                         "going on in the same destination streams where the one before stopped (stream_fill / "
+                         "open_round_base) -- a step of chunks x records records.  Variable-width batches stay "
+                         "under 4 GiB (32-bit record offsets); this is how 1e8..1e9 of them are packed.")
     ap.add_argument("--exchange", default="batch", choices=["batch", "rounds"],
                     help="N > 1, streams layout: batch = everything a destination gets from this rank in the "
                          "whole batch as ONE message (its rounds lie back to back in the stream; the rounds come "
@@ -268,17 +273,19 @@ def main():
         rounds_note = "one round holds the batch"
     stride = P * buf_size
     streams_layout = bool(comm_size) and args.layout == "streams"
+    chunks = max(1, args.chunks) if streams_layout else 1
+    max_rounds = max_rounds * chunks
     pk = DevicePacker(lay, P, self_rank, buf_size, max_records=n, device=dev)
     if streams_layout:
         # one stream per destination, sized for its share of the batch plus slack
-        stream_cap = (int(total_bytes * hot_share) + total_bytes // 64 + 65536) // 16 * 16
+        stream_cap = (chunks * int(total_bytes * hot_share) + total_bytes // 64 + 65536) // 16 * 16
         images = torch.empty(P * stream_cap, dtype=torch.uint8, device=f"cuda:{dev}")
         rounds_note += "; rounds are views into one stream per destination"
     else:
         images = torch.empty(max_rounds * stride, dtype=torch.uint8, device=f"cuda:{dev}")
     local = recv = None
     if distributed:
-        local = torch.empty(int(total_bytes * hot_share) + total_bytes // 64 + 65536, dtype=torch.uint8,
+        local = torch.empty(chunks * int(total_bytes * hot_share) + total_bytes // 64 + 65536, dtype=torch.uint8,
                             device=f"cuda:{dev}")
         batch_exchange = streams_layout and args.exchange == "batch"
         # batch: one receive stream per source; else one receive image per round
@@ -291,14 +298,30 @@ def main():
     def step():
         t0 = time.perf_counter()
         if streams_layout:
-            r = pk.pack_streams(records, n, images, stream_cap, max_rounds, rec_off=rec_off, local_out=local)
+            from mimir_amd.packer import merge_stream_rounds
+            r, fill, base, lused, kms = None, None, None, 0, 0.0
+            for _ in range(chunks):
+                rc_ = pk.pack_streams(records, n, images, stream_cap, max_rounds, rec_off=rec_off, stream_fill=fill,
+                                      open_round_base=base, local_out=None if local is None else local[lused:])
+                if rc_.next != n:
+                    raise RuntimeError(f"{rc_.n_rounds} rounds used up at record {rc_.next} of {n}: raise max_rounds")
+                kms += pk.last_kernel_ms()
+                lused += rc_.local_bytes
+                base = rc_.round_base[-1].copy()
+                fill = base + rc_.round_send_offset[-1]
+                if self_rank >= 0:
+                    fill[self_rank] = 0
+                r = merge_stream_rounds(r, rc_)
+            pack_s.append(time.perf_counter() - t0)
+            kernel_ms.append(kms)
+            stats["rounds"] = r.n_rounds
         else:
             r = pk.pack_rounds(records, n, images, stride, max_rounds, rec_off=rec_off, local_out=local, algo=algo)
-        pack_s.append(time.perf_counter() - t0)
-        if r.next != n:
-            raise RuntimeError(f"{r.n_rounds} rounds used up at record {r.next} of {n}: raise max_rounds")
-        kernel_ms.append(pk.last_kernel_ms())
-        stats["rounds"] = r.n_rounds
+            pack_s.append(time.perf_counter() - t0)
+            if r.next != n:
+                raise RuntimeError(f"{r.n_rounds} rounds used up at record {r.next} of {n}: raise max_rounds")
+            kernel_ms.append(pk.last_kernel_ms())
+            stats["rounds"] = r.n_rounds
         if distributed:
             so = r.round_send_offset
             part, bases = (stream_cap, r.round_base) if streams_layout else (buf_size, None)
@@ -336,7 +359,8 @@ def main():
         dt = float(t.item())
 
     ms_per_step = dt / args.steps * 1e3
-    value = n * world * args.steps / dt
+    value = n * chunks * world * args.steps / dt
+    algo_bytes *= chunks
     in_kernel = (pk.last_algo() in ("onesweep16", "onesweepd") or max_rounds == 1 or stats["rounds"] == 1
                  or streams_layout)
     # one kernel covers the step (16-byte records cut their rounds inside the kernel); the
@@ -362,13 +386,14 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": data,
-        "GBps_algorithmic": value * algo_bytes / n / 1e9,
+        "GBps_algorithmic": value * algo_bytes / (n * chunks) / 1e9,
         "config": {
             "workload": (what + f", hash-partition+pack into {P} destination partitions"
                          + ((", then RCCL all-to-all" if backend == "nccl" else
                              ", then a gloo exchange through host memory (rehearsal, not xGMI)")
                             if distributed else "")),
-            "records_per_gpu": n, "record_bytes": total_bytes / n, "partitions": P,
+            "records_per_gpu": n * chunks, "record_bytes": total_bytes / n, "partitions": P,
+            "calls_per_step": chunks,
             "local_bypass": distributed, "kernel_variant": kname,
             "partition_bytes": buf_size, "rounds": stats["rounds"], "rounds_note": rounds_note,
             "layout": "streams" if streams_layout else ("images" if comm_size else "one round"),
@@ -380,7 +405,7 @@ def main():
                      "algorithmic_bytes_per_launch": algo_bytes},
     }
     if distributed:
-        pack_only = n * world / (sum(pack_s) / len(pack_s))
+        pack_only = n * chunks * world / (sum(pack_s) / len(pack_s))
         out["pack_only_records_per_s"] = pack_only
         xfer_s = dt / args.steps - sum(pack_s) / len(pack_s)
         hot = stats["sent_max"]   # bytes of the busiest (this rank -> peer) pair over the whole step

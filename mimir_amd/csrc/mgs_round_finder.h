@@ -240,20 +240,21 @@ __device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, S
                 const uint32_t i = rs * 64u + (uint32_t) lane;
                 const uint32_t d = x->dest[i], u = x->units[i];
                 const bool act = d != 0xFFu;
-                // units of each record's column up to and including the record
-                unsigned long long upto = 0;
-                uint64_t rem = __ballot(act);
-                while (rem) { // one trip per distinct destination of the row
-                    const int leader = __ffsll((unsigned long long) rem) - 1;
-                    const uint32_t b = (uint32_t) __shfl((int) d, leader);
-                    const bool inb = act && d == b;
+                // Only a column that passes its limit in this row can hold the cut (nearly always one
+                // column): per such column, the running units of its records up to and including each
+                const uint32_t cn_rs = x->rowcnt[rs][lane];
+                uint64_t cand = __ballot(is_part && run + cn_rs > lim);
+                bool over = false;
+                while (cand) {
+                    const int b = __ffsll((unsigned long long) cand) - 1;
+                    cand &= cand - 1;
+                    const bool inb = act && d == (uint32_t) b;
                     const uint32_t inc = wave_incl_scan_u32(inb ? u : 0u, lane);
-                    const unsigned long long run_b = (unsigned long long) __shfl((long long) run, (int) b);
-                    if (inb) upto = run_b + inc;
-                    rem &= ~__ballot(inb);
+                    const unsigned long long run_b = (unsigned long long) __shfl((long long) run, b);
+                    const unsigned long long lim_b = (unsigned long long) __shfl((long long) lim, b);
+                    if (inb && run_b + inc > lim_b) over = true;
                 }
-                const unsigned long long lim_d = (unsigned long long) __shfl((long long) lim, (int) (d & 63u));
-                const uint64_t om = __ballot(act && upto > lim_d);
+                const uint64_t om = __ballot(over);
                 if (!om) { // cannot happen: the row's totals said otherwise
                     r0 = rs + 1;
                     continue;

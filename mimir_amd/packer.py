@@ -49,6 +49,30 @@ class RoundsResult:
         self.round_local_bytes = lbytes[:n].copy()
 
 
+def merge_stream_rounds(a, b):
+    """The rounds of two consecutive streams-layout calls on the same destination streams
+    (the second started with stream_fill / open_round_base taken from the first) as one
+    table: the first round of b is the open round of a going on."""
+    if a is None:
+        return b
+    assert np.array_equal(a.round_base[-1], b.round_base[0]), "the second call did not go on in the open round"
+    m = RoundsResult.__new__(RoundsResult)
+    m.n_rounds = a.n_rounds + b.n_rounds - 1
+    m.next = b.next
+    m.packed_records = a.packed_records + b.packed_records
+    m.local_records = a.local_records + b.local_records
+    m.local_bytes = a.local_bytes + b.local_bytes
+    m.round_next = np.concatenate([a.round_next[:-1], b.round_next])
+    m.round_send_offset = np.concatenate([a.round_send_offset[:-1], b.round_send_offset])
+    m.round_base = np.concatenate([a.round_base[:-1], b.round_base])
+    lr, lb = b.round_local_records.copy(), b.round_local_bytes.copy()
+    lr[0] += a.round_local_records[-1]
+    lb[0] += a.round_local_bytes[-1]
+    m.round_local_records = np.concatenate([a.round_local_records[:-1], lr])
+    m.round_local_bytes = np.concatenate([a.round_local_bytes[:-1], lb])
+    return m
+
+
 class DevicePacker:
     """One rank's pack state (mgs_handle) on one GPU.
 

@@ -245,3 +245,58 @@ def test_streams_record_larger_than_partition(oracle):
         pk.pack_streams(torch.from_numpy(blob).cuda(), n, streams, 2 * len(blob), 4096, rec_off=d_off)
     assert e.value.status == capi.ERR_RECORD_SIZE
     pk.close()
+
+
+@pytest.mark.parametrize("kind", ["u64", "words"])
+def test_streams_chained_calls(oracle, kind):
+    """A stream of records handed over in three calls that go on in the same destination
+    streams (stream_fill = where the last call stopped, open_round_base = where its open
+    round began): the rounds, taken together, are those of one call over everything."""
+    import torch
+    from mimir_amd.packer import DevicePacker
+    n, P, rank = 90_000, 4, 2
+    if kind == "u64":
+        blob, offs, lay = datagen.u64_records(n, seed=51)
+        buf = 16 * 2500
+    else:
+        blob, offs, lay = datagen.word_records(n, n_unique=2000, alpha=1.0, len_mean=6, len_sd=1, seed=52)
+        buf = 40_000
+    glay, olay = capi.Layout.make(*lay), O.Layout.make(*lay)
+    want, _ = oracle_rounds(oracle, olay, blob, offs, n, P, rank, buf)
+    cap = (len(blob) + 4096) // 16 * 16
+    pk = DevicePacker(glay, P, rank, buf, max_records=n)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob).to(dev)
+    d_off = None if offs is None else torch.from_numpy(offs.astype(np.uint32).view(np.int32)).to(dev)
+    streams = torch.full((P * cap,), 0xEE, dtype=torch.uint8, device=dev)
+    local = torch.empty(len(blob), dtype=torch.uint8, device=dev)
+    fill = base = None
+    rounds, lused = [], 0   # (base row, send_offset row, next, local records) of every round, merged over the calls
+    for n_end in (n // 3 + 5, 2 * n // 3 + 1, n):
+        start = rounds[-1][2] if rounds else 0
+        got = pk.pack_streams(d_blob, n_end, streams, cap, 64, start=start, rec_off=d_off, stream_fill=fill,
+                              open_round_base=base, local_out=local[lused:])
+        assert got.next == n_end
+        for k in range(got.n_rounds):
+            row = (got.round_base[k].copy(), got.round_send_offset[k].copy(), int(got.round_next[k]),
+                   int(got.round_local_records[k]))
+            if k == 0 and rounds:   # the open round of the call before goes on
+                prev = rounds.pop()
+                assert np.array_equal(prev[0], row[0])
+                row = (row[0], row[1], row[2], prev[3] + row[3])
+            rounds.append(row)
+        lused += got.local_bytes
+        base = got.round_base[got.n_rounds - 1].copy()
+        fill = base + got.round_send_offset[got.n_rounds - 1]
+        fill[rank] = 0
+    assert len(rounds) == len(want)
+    img = streams.cpu().numpy()
+    for k, w in enumerate(want):
+        b, so, nxt, lrec = rounds[k]
+        assert nxt == w["next"] and so.tolist() == w["send_offset"].tolist() and lrec == w["local_records"], f"round {k}"
+        for p in range(P):
+            if p != rank:
+                o = p * cap + int(b[p])
+                assert np.array_equal(img[o:o + int(so[p])], w["partitions"][p]), f"round {k} partition {p}"
+    assert np.array_equal(local.cpu().numpy()[:lused], np.concatenate([w["local"] for w in want]))
+    pk.close()
