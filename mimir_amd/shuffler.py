@@ -260,6 +260,116 @@ class GpuShuffler:
                 break
 
 
+class StreamsGpuShuffler:
+    """CollectiveShuffler for a map whose emitted records are device-resident batches (the
+    output of mgs_tokenize_device, or any wire-form record stream in HBM): no record ever
+    crosses the per-record write(key*, val*) boundary.
+
+        open()
+        write_device_records(d_blob, n, d_rec_off=None)   any number of times, emit order
+        close()
+
+    Every batch is packed with mgs_pack_streams_device into one stream per destination,
+    going on where the batch before stopped, so the rounds are those CollectiveShuffler::write
+    would cut over the whole sequence of records (src/collectiveshuffler.h:131-166).  close()
+    moves everything in one all-to-all-v (exchange_streams) and hands the sink what the
+    reference's `out` sees, in its order: the local records of round k (emitted during it,
+    :135-141), then round k's receive image source by source (:563-585), for k = 0, 1, ...
+    shuffle_times, kvcount and the byte counters are those of the reference's exchanges.
+    The whole map's partitions stay in HBM until close(): size stream_bytes for them."""
+
+    def __init__(self, out, layout, group=None, comm_buf_size=64 << 20, device=0, stream_bytes=1 << 30,
+                 max_records=1 << 26, max_rounds=4096):
+        if out is None:
+            raise ValueError("Output shuffler cannot be NULL!")  # src/baseshuffler.h:35
+        self.out, self.layout, self.group, self.device = out, layout, group, device
+        self.shuffle_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.shuffle_rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.buf_size, self.unit_size, self.type_log_bytes = capi.geometry(comm_buf_size, self.shuffle_size)
+        self.stream_cap = int(stream_bytes) // 16 * 16
+        self.max_records, self.max_rounds = int(max_records), int(max_rounds)
+        self.kvcount = self.shuffle_times = self.send_bytes = self.recv_bytes = 0
+
+    def open(self):
+        from .packer import DevicePacker
+        P = self.shuffle_size
+        self.dev = torch.device("cuda", self.device)
+        self.packer = DevicePacker(self.layout, P, self.shuffle_rank, self.buf_size, self.max_records,
+                                   device=self.device)
+        self.streams = torch.empty(P * self.stream_cap, dtype=torch.uint8, device=self.dev)
+        self.local = torch.empty(self.stream_cap, dtype=torch.uint8, device=self.dev)
+        self._rounds, self._fill, self._base, self._lused = None, None, None, 0
+        return True
+
+    def write_device_records(self, d_blob, n, d_rec_off=None):
+        from .packer import merge_stream_rounds
+        start = 0
+        while start < n:
+            r = self.packer.pack_streams(d_blob, n, self.streams, self.stream_cap, self.max_rounds, start=start,
+                                         rec_off=d_rec_off, stream_fill=self._fill, open_round_base=self._base,
+                                         local_out=self.local[self._lused:])
+            if r.next == start and r.n_rounds >= self.max_rounds:
+                raise capi.MgsError(capi.ERR_ARG, "max_rounds too small for this batch")
+            if r.next < n and r.n_rounds < self.max_rounds:
+                raise capi.MgsError(capi.ERR_ARG, "a destination stream is full: raise stream_bytes")
+            self._lused += r.local_bytes
+            self._base = r.round_base[-1].copy()
+            self._fill = self._base + r.round_send_offset[-1]
+            if self.shuffle_rank < len(self._fill):
+                self._fill[self.shuffle_rank] = 0
+            self._rounds = merge_stream_rounds(self._rounds, r)
+            start = r.next
+        return True
+
+    def get_record_count(self):
+        return self.kvcount
+
+    def _deliver(self, blob, src):
+        offs = wire_offsets(self.layout, blob)
+        if hasattr(self.out, "write_records_from"):
+            self.out.write_records_from(src, blob, offs)
+        else:
+            self.out.write_records(blob, offs)
+
+    def close(self):
+        from .exchange import exchange_streams
+        P, me = self.shuffle_size, self.shuffle_rank
+        R_mine = self._rounds
+        so = R_mine.round_send_offset if R_mine is not None else np.zeros((1, P), dtype=np.int64)
+        base = R_mine.round_base if R_mine is not None else np.zeros((1, P), dtype=np.int64)
+        lbytes = R_mine.round_local_bytes if R_mine is not None else np.zeros(1, dtype=np.int64)
+        self.kvcount = int(R_mine.packed_records) if R_mine is not None else 0
+        self.send_bytes = int(so.sum())
+        local = self.local[:self._lused].cpu().numpy()
+        if P == 1 or not dist.is_initialized():
+            self._deliver(local, me)
+            self.shuffle_times = so.shape[0]
+            self.packer.close()
+            return
+        backend = dist.get_backend(self.group)
+        torch.cuda.current_stream(self.dev).synchronize()
+        src = self.streams if backend == "nccl" else self.streams.cpu()
+        # receive streams: a source sends this rank at most what its own stream for it holds
+        need = torch.tensor([int(so.sum(axis=0).max())], dtype=torch.int64, device=src.device)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX, group=self.group)
+        rcap = max(int(need.item()), 16)
+        recv = torch.empty(P * rcap, dtype=torch.uint8, device=src.device)
+        rc, rb, R = exchange_streams(src, self.stream_cap, so, base, recv, rcap, group=self.group)
+        self.recv_bytes = int(rc.sum())
+        self.shuffle_times = R
+        host = recv.cpu().numpy()
+        lpos = 0
+        for k in range(R):
+            if k < len(lbytes) and lbytes[k]:
+                self._deliver(local[lpos:lpos + int(lbytes[k])], me)
+                lpos += int(lbytes[k])
+            for s in range(P):
+                if s != me and rc[k, s]:
+                    o = s * rcap + int(rb[k, s])
+                    self._deliver(host[o:o + int(rc[k, s])], s)
+        self.packer.close()
+
+
 class CombineGpuShuffler(GpuShuffler):
     """CombineCollectiveShuffler (src/combinecollectiveshuffler.h) for a combiner
     declared as one of capi.COMBINE_* instead of a user callback: in a round only

@@ -14,6 +14,14 @@ def test_gpu_shuffle_matches_reference_simulation(oracle, P, kind):
     run_case(oracle, P, kind, comm=16384, use_gpu=True)
 
 
+@pytest.mark.parametrize("P,kind", [(2, "u64"), (3, "words"), (4, "oct"), (2, "join")])
+def test_gpu_streams_shuffler_matches_reference_simulation(oracle, P, kind):
+    """StreamsGpuShuffler: device-resident batches, rounds as views into destination streams,
+    one all-to-all-v for the whole map -- the sink still sees what the reference's `out` sees,
+    in its order, and the counters are those of the reference's exchanges."""
+    run_case(oracle, P, kind, comm=16384, use_gpu="streams")
+
+
 def test_gpu_shuffle_default_geometry(oracle):
     """The reference's default 64 MiB buffer: buf_size 32 MiB at P = 2."""
     # about 4.5 MiB of non-local records per rank against 32 MiB partitions:

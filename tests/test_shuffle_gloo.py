@@ -50,10 +50,30 @@ def _worker(rank, P, port, kind, comm, outdir, use_gpu, counts, combine_op=None)
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=P)
     try:
-        from mimir_amd.shuffler import CombineGpuShuffler, GpuShuffler, ListSink
+        from mimir_amd.shuffler import CombineGpuShuffler, GpuShuffler, ListSink, StreamsGpuShuffler
         n = counts[rank]
         blob, offs, lay = make_stream(kind, rank, n)
         sink = ListSink()
+        if use_gpu == "streams":
+            # device-resident batches through the streams layout, uneven on purpose
+            sh = StreamsGpuShuffler(sink, lay, comm_buf_size=comm, stream_bytes=1 << 20, max_records=1 << 16)
+            sh.open()
+            d_blob = torch.from_numpy(np.ascontiguousarray(blob)).cuda() if n else torch.empty(16, dtype=torch.uint8,
+                                                                                                device="cuda")
+            d_off = None if offs is None else torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+            for a, b in zip([0, n // 3], [n // 3, n]):
+                if b > a:
+                    fl = lay.fixed_len()
+                    if fl:
+                        sh.write_device_records(d_blob[a * fl:], b - a)
+                    else:
+                        sh.write_device_records(d_blob, b - a, d_off[a:])
+            sh.close()
+            with open(os.path.join(outdir, f"rank{rank}.pkl"), "wb") as f:
+                pickle.dump({"records": sink.records, "kvcount": sh.get_record_count(),
+                             "shuffle_times": sh.shuffle_times, "send_bytes": sh.send_bytes,
+                             "recv_bytes": sh.recv_bytes}, f)
+            return
         factory = None if use_gpu else refsim.OraclePacker
         if combine_op is None:
             sh = GpuShuffler(sink, lay, comm_buf_size=comm, stage_bytes=1 << 16,
