@@ -1407,7 +1407,8 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     const size_t need = up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t))
                         + up(((size_t) p.nchunks + 1) * sizeof(uint64_t)) + up((size_t) p.nchunks * S * sizeof(uint32_t))
                         + up((size_t) p.nchunks * sizeof(uint32_t))
-                        + up(tables * sizeof(uint16_t)) + up(tables);
+                        + up(tables * sizeof(uint16_t)) + up(tables)
+                        + up((size_t) p.nchunks * (size_t) (p.chunk_bytes / 8));
     if (h->pending) { // the control block and the scratch are shared with the pack call in flight
         h->err = "mgs_unpack_device: a pack call is in flight on this handle (call mgs_pack_result first)";
         return MGS_ERR_STATE;
@@ -1421,6 +1422,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     p.entry = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * sizeof(uint32_t));
     p.piece_count = reinterpret_cast<uint16_t *>(q);          q += up(tables * sizeof(uint16_t));
     p.piece_exit = q;                                         q += up(tables);
+    p.masks = reinterpret_cast<unsigned long long *>(q);      q += up((size_t) p.nchunks * (size_t) (p.chunk_bytes / 8));
     p.rec_off = d_rec_off;
     p.rec_cap = rec_off_capacity;
     p.ctrl = h->d_ctrl;

@@ -56,6 +56,8 @@ struct UnpParams {
     uint32_t *table;      // [nchunks][V+2]: exit state << 24 | records, per entry state
     uint8_t *piece_exit;  // [nchunks][64][V+2]
     uint16_t *piece_count; // [nchunks][64][V+2]
+    unsigned long long *masks; // [nchunks][piece_bytes / 64][64]: NUL mask of every 64-byte block of every piece,
+                               // left by k_unp_spec for k_unp_emit (an eighth of the stream, so that it is read once)
     uint32_t *entry;      // [nchunks] entry state of each chunk
     uint64_t *first_rec;  // [nchunks+1] index of the chunk's first record start (+ total)
     uint32_t *rec_off;    // out: rec_off[i] = start of record i; rec_off[n] = nbytes
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
         const UnpRows cur = rows;
         if (b + 1 < nb) unp_rows_load(p, c0, b + 1, lane, rows); // in flight during the parse
         const uint64_t nul = unp_rows_mask(p, c0, b, lane, cur, smask);
+        p.masks[((uint64_t) c * nb + b) * 64 + lane] = nul; // one 512-byte row per step: k_unp_emit parses from these
         const uint64_t boff = a0 + 64u * b;
         if (boff >= a1) continue;
         const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
@@ -369,13 +372,16 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
     const uint32_t c = blockIdx.x, V = p.V, S = V + 2;
     if (p.ctrl->head.error != 0) return;
     uint32_t *stab = unp_lds;
-    uint16_t *smask = reinterpret_cast<uint16_t *>(unp_lds + UNP_PIECES * S);
     const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
     const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
     const uint64_t a1 = min(p.nbytes, a0 + p.piece_bytes);
     const uint32_t nb = p.piece_bytes / 64;
-    UnpRows rows;
-    unp_rows_load(p, c0, 0, lane, rows);
+    // the NUL masks k_unp_spec left (the stream itself is not read again), a few blocks ahead
+    constexpr uint32_t AHEAD = 4;
+    const unsigned long long *mrow = p.masks + (uint64_t) c * nb * 64 + lane;
+    unsigned long long mq[AHEAD];
+#pragma unroll
+    for (uint32_t j = 0; j < AHEAD; j++) mq[j] = (j < nb) ? mrow[(uint64_t) j * 64] : 0ull;
     for (uint32_t i = lane; i < UNP_PIECES * S; i += 64)
         stab[i] = ((uint32_t) p.piece_exit[(uint64_t) c * UNP_PIECES * S + i] << 16)
                   | p.piece_count[(uint64_t) c * UNP_PIECES * S + i];
@@ -397,14 +403,17 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
     sink.slot = unp_lds + ((UNP_PIECES * S + 128 + 3) & ~3u) + UNP_SLOT_PITCH * lane;
     sink.out = p.rec_off - back;
     sink.v = sink.v_first = p.first_rec[c] + base + back;
-    for (uint32_t b = 0; b < nb; b++) {
-        const UnpRows now = rows;
-        if (b + 1 < nb) unp_rows_load(p, c0, b + 1, lane, rows); // in flight during the parse
-        const uint64_t nul = unp_rows_mask(p, c0, b, lane, now, smask);
-        const uint64_t boff = a0 + 64u * b;
-        if (boff >= a1) continue;
-        const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
-        state = unp_step(nul, state, V, valid, [&](uint32_t pos) { sink.put((uint32_t) boff + pos); });
+    for (uint32_t b0 = 0; b0 < nb; b0 += AHEAD) {
+#pragma unroll
+        for (uint32_t j = 0; j < AHEAD; j++) {
+            const uint32_t b = b0 + j;
+            const uint64_t nul = mq[j];
+            if (b + AHEAD < nb) mq[j] = mrow[(uint64_t) (b + AHEAD) * 64]; // in flight during the parse
+            const uint64_t boff = a0 + 64u * b;
+            if (b >= nb || boff >= a1) continue;
+            const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
+            state = unp_step(nul, state, V, valid, [&](uint32_t pos) { sink.put((uint32_t) boff + pos); });
+        }
     }
     sink.finish();
     if (c == p.nchunks - 1 && lane == 0) p.rec_off[p.first_rec[p.nchunks]] = (uint32_t) p.nbytes;

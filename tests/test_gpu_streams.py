@@ -300,3 +300,27 @@ def test_streams_chained_calls(oracle, kind):
                 assert np.array_equal(img[o:o + int(so[p])], w["partitions"][p]), f"round {k} partition {p}"
     assert np.array_equal(local.cpu().numpy()[:lused], np.concatenate([w["local"] for w in want]))
     pk.close()
+
+
+def test_streams_empty_call_and_wrong_result_call(oracle):
+    import torch
+    from mimir_amd.packer import DevicePacker
+    n, P = 1000, 4
+    blob, _, lay = datagen.u64_records(n, seed=61)
+    pk = DevicePacker(capi.Layout.make(*lay), P, 1, 16 * 100, max_records=n)
+    streams = torch.empty(P * 16 * n, dtype=torch.uint8, device="cuda:0")
+    local = torch.empty(16 * n, dtype=torch.uint8, device="cuda:0")
+    d = torch.from_numpy(blob).cuda()
+    fill = np.array([160, 0, 320, 16], dtype=np.int64)
+    base = np.array([0, 0, 160, 16], dtype=np.int64)
+    r = pk.pack_streams(d, 500, streams, 16 * n, 8, start=500, stream_fill=fill, open_round_base=base, local_out=local)
+    assert r.n_rounds == 1 and r.next == 500 and r.packed_records == 0
+    assert r.round_send_offset[0].tolist() == [160, 0, 160, 0] and r.round_base[0].tolist() == [0, 0, 160, 16]
+    # a streams call in flight answers only to the streams result call
+    pk.pack_streams_async(d, n, streams, 16 * n, 64, local_out=local)
+    with pytest.raises(capi.MgsError) as e:
+        pk.rounds_result()
+    assert e.value.status == capi.ERR_STATE
+    got = pk.streams_result()
+    assert got.next == n and got.n_rounds > 1
+    pk.close()
