@@ -1093,7 +1093,7 @@ int mgs_pack_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_
 // Which kernel cuts the rounds of this call itself?  MGS_ALGO_ONESWEEP16 / MGS_ALGO_ONESWEEPV
 // (same conditions as in pack_enqueue), or 0: one kernel sequence per round.
 static int rounds_in_kernel(const mgs_handle *h, const void *d_records, void *d_send_images, int64_t image_stride,
-                            void *d_local_out, const int64_t *init_offset, int algo)
+                            void *d_local_out, const int64_t *init_offset, int algo, uint32_t max_rounds)
 {
     const mgs_desc &D = h->desc;
     bool os16 = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEP16) && kOsVariants[h->os_variant].agg16
@@ -1104,7 +1104,8 @@ static int rounds_in_kernel(const mgs_handle *h, const void *d_records, void *d_
     for (int b = 0; b < D.nranks && os16 && init_offset; b++) os16 = (init_offset[b] % 16) == 0;
     if (os16) return MGS_ALGO_ONESWEEP16;
     if (algo == MGS_ALGO_ONESWEEP16) return 0;
-    const bool osd = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEPV) && !osv_image_kernel(h, 2)
+    // (a one-round call of the byte-granular layouts runs the LDS-image kernel through mgs_pack_device)
+    const bool osd = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEPV) && !osv_image_kernel(h, max_rounds)
                      && D.nranks + (D.rank >= 0 ? 1 : 0) <= OS_MAXP
                      && (h->fixed_len == 0 || od_pick_k((double) h->fixed_len) != 0);
     return osd ? MGS_ALGO_ONESWEEPV : 0;
@@ -1120,7 +1121,8 @@ int mgs_pack_rounds_device_async(mgs_handle *h, const void *d_records, const uin
         h->err = "mgs_pack_rounds_device: max_rounds >= 1 and image_stride >= nranks * buf_size required";
         return MGS_ERR_ARG;
     }
-    const int in_kernel = rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo);
+    const int in_kernel = rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo,
+                                           max_rounds);
     if (!in_kernel) {
         h->err = "mgs_pack_rounds_device_async: this layout / rank count packs one round per kernel sequence; "
                  "use the blocking mgs_pack_rounds_device";
@@ -1278,7 +1280,7 @@ int mgs_pack_rounds_device(mgs_handle *h, const void *d_records, const uint32_t 
         h->err = "mgs_pack_rounds_device: max_rounds >= 1 and image_stride >= nranks * buf_size required";
         return MGS_ERR_ARG;
     }
-    if (rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo)) {
+    if (rounds_in_kernel(h, d_records, d_send_images, image_stride, d_local_out, init_offset, algo, max_rounds)) {
         int rc = mgs_pack_rounds_device_async(h, d_records, d_rec_off, n_end, start, init_offset, d_send_images,
                                               image_stride, max_rounds, d_local_out, local_cap, d_dest_out, algo,
                                               stream);

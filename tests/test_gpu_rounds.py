@@ -164,3 +164,18 @@ def test_rounds_async_pair(oracle):
             o, so = k * P * buf + p * buf, int(got.round_send_offset[k][p])
             assert torch.equal(images[o:o + so], ref_img[o:o + so])
     pk.close()
+
+
+@pytest.mark.parametrize("kind", ["words", "oct12"])
+def test_rounds_call_with_one_round(oracle, kind):
+    """max_rounds = 1 through the rounds entry point: the byte-granular layouts then run the
+    one-round kernel (the call used to be refused as 'a one-round call')."""
+    n = 30_000
+    if kind == "words":
+        blob, offs, lay = datagen.word_records(n, n_unique=3000, alpha=1.0, len_mean=6, len_sd=1, seed=21)
+    else:
+        blob, offs, lay = datagen.octree_records(n, level=12, seed=22)
+    got = check_rounds(oracle, blob, offs, lay, n, 4, 1, (len(blob) // 4 // 3) // 16 * 16, max_rounds=1)
+    assert got.n_rounds == 1 and got.next < n
+    got = check_rounds(oracle, blob, offs, lay, n, 4, -1, len(blob), max_rounds=1)   # the whole batch fits
+    assert got.n_rounds == 1 and got.next == n
