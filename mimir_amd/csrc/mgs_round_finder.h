@@ -221,21 +221,30 @@ __device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, S
             unsigned long long run = hi_val - tot; // lane = column: units before the tile
             uint32_t r0 = 0;
             for (;;) {
-                // the first row at whose end a partition is past its limit
+                // Columns that pass their limit before the tile ends (hi_val: the totals at its end).
+                // For each (nearly always one) the rows' counts are scanned with lane = row: the
+                // first row at whose end the column is past its limit; the cut lies in the earliest.
+                uint64_t cc = __ballot(is_part && hi_val > lim);
+                if (!cc) break; // no (further) cut in this tile
                 uint32_t rs = rows;
-                unsigned long long acc = run;
-                for (uint32_t r = r0; r < rows && rs == rows; r += 8) { // eight rows' counts in flight at a time
-                    uint32_t cn[8];
-#pragma unroll
-                    for (uint32_t jj = 0; jj < 8; jj++) cn[jj] = (r + jj < rows) ? x->rowcnt[r + jj][lane] : 0u;
-#pragma unroll
-                    for (uint32_t jj = 0; jj < 8; jj++) {
-                        if (rs != rows || r + jj >= rows) continue;
-                        if (__ballot(is_part && acc + cn[jj] > lim)) rs = r + jj;
-                        else acc += cn[jj];
+                const bool my_row = (uint32_t) lane >= r0 && (uint32_t) lane < rows;
+                while (cc) {
+                    const int b = __ffsll((unsigned long long) cc) - 1;
+                    cc &= cc - 1;
+                    const uint32_t inc = wave_incl_scan_u32(my_row ? x->rowcnt[lane][b] : 0u, lane);
+                    const unsigned long long run_b = (unsigned long long) __shfl((long long) run, b);
+                    const unsigned long long lim_b = (unsigned long long) __shfl((long long) lim, b);
+                    const uint64_t cr = __ballot(my_row && run_b + inc > lim_b);
+                    if (cr) {
+                        const uint32_t r = (uint32_t) (__ffsll((unsigned long long) cr) - 1);
+                        rs = r < rs ? r : rs;
                     }
                 }
-                if (rs == rows) break; // no (further) cut in this tile
+                if (rs == rows) break; // cannot happen: the tile's totals said otherwise
+                // totals at the start of row rs
+                unsigned long long acc = run;
+#pragma unroll 8
+                for (uint32_t r = r0; r < rs; r++) acc += x->rowcnt[r][lane];
                 run = acc;
                 const uint32_t i = rs * 64u + (uint32_t) lane;
                 const uint32_t d = x->dest[i], u = x->units[i];
