@@ -825,7 +825,9 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             c.ctrl = d_ctrl;
             MGS_HIP(h, hipMemsetAsync(d_status, 0, (size_t) c.ntiles * columns * sizeof(unsigned long long), stream));
             MGS_HIP(h, hipMemsetAsync(d_agg16, 0, ((size_t) c.ntiles << c.lpt_log) * sizeof(unsigned long long), stream));
-            uint32_t grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2));
+            const uint32_t wg_per_cu = 2u;
+            q.in_bytes = (uint32_t) OV_IN_BYTES;
+            uint32_t grid = std::min<uint32_t>(c.ntiles, (uint32_t) h->num_cus * wg_per_cu);
             if (sa) {
                 // streams layout: the sweep packs one round (the streams); workgroup 0 finds the rounds
                 rc = ensure_round_tables(h, max_rounds, columns, P, true);
@@ -838,7 +840,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                 c.f_cap = (unsigned long long) D.buf_size;
                 MGS_HIP(h, hipMemsetAsync(h->d_rt, 0, round_table_words(max_rounds, columns, true) * sizeof(unsigned long long),
                                           stream));
-                grid = std::min<uint32_t>(c.ntiles, (uint32_t) (h->num_cus * 2) - 1u) + 1u;
+                grid = std::min<uint32_t>(c.ntiles, (uint32_t) h->num_cus * wg_per_cu - 1u) + 1u;
             }
             const mgs_layout &L = D.layout;
             // layout mode 1: ONE string key and a fixed-width or absent value

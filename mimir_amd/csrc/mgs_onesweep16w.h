@@ -503,9 +503,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
 
     if (p.finder && blockIdx.x == 0) {
         // streams layout: this workgroup finds the rounds instead of sweeping
-        static_assert(sizeof(FinderLds) <= sizeof(srec), "the finder's tables live in the tile image");
+        typedef FinderLdsT<TILE / 64> FL;
+        static_assert(sizeof(FL) <= sizeof(srec), "the finder's tables live in the tile image");
         FinderSrc16 src{p};
-        os_round_finder<FinderSrc16, THREADS / 64, TILE / 64>(p, P, src, reinterpret_cast<FinderLds *>(srec), tid);
+        os_round_finder<FinderSrc16, THREADS / 64, TILE / 64>(p, P, src, reinterpret_cast<FL *>(srec), tid);
         return;
     }
 

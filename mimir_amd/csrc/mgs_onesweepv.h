@@ -67,6 +67,7 @@ struct OvParams {
     // address ranges (send images, local stream); a store that does not is counted, not made
     uint64_t dbg_lo[2], dbg_hi[2];
     uint32_t dbg_flags; // timing experiments (wrong output): 1 = no fast-path stores, 2 = only the first store of a record
+    uint32_t in_bytes;  // LDS staging capacity of the kernel instantiation that serves the call (k_onesweepv)
 };
 
 struct __attribute__((packed)) OvU16 { uint16_t v; };
@@ -180,7 +181,7 @@ __global__ void k_osv_check(OvParams q)
     const uint64_t i0 = (uint64_t) t * T, i1 = min(q.n, i0 + T);
     const uint64_t s = ov_offset(q, i0), e = ov_offset(q, i1);
     const uint64_t shift = ((uintptr_t) q.blob + s) & 15u;
-    if (e < s || e - s + shift > (uint64_t) OV_IN_BYTES)
+    if (e < s || e - s + shift > (uint64_t) q.in_bytes)
         __hip_atomic_store(&q.os.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -201,7 +202,7 @@ struct FinderSrcV {
         const uintptr_t a0 = ((uintptr_t) q.blob + s) & ~(uintptr_t) 15;
         shift = (uint32_t) (((uintptr_t) q.blob + s) & 15u);
         span = (e >= s ? e - s : 0) + shift;
-        if (span > (uint64_t) OV_IN_BYTES) span = 0; // k_osv_check has sent such a call to the generic path
+        if (span > (uint64_t) q.in_bytes) span = 0; // k_osv_check has sent such a call to the generic path
         const uint32_t nch = (uint32_t) ((span + 15) >> 4);
         __syncthreads(); // the previous tile's bytes are no longer read
         for (uint32_t ch = (uint32_t) tid; ch < nch; ch += (uint32_t) nthreads)
@@ -243,14 +244,16 @@ struct FinderSrcV {
 // LM (layout mode) spares the per-record layout decisions: 1 = string key(s) and a
 // fixed-width or absent value (key = the record minus the value, ends with a NUL);
 // 2 = fixed-width key and a fixed-width or absent value; 0 = any layout.
-template <int THREADS, int K, int VAR, int MINW, int LOOK, int LM>
+// INB: bytes of the LDS staging buffer (and of the image).  The default holds a tile of 448 * K records
+// of up to 80 / K bytes at two workgroups per compute unit; half of it, with K = 2, fits three.
+template <int THREADS, int K, int VAR, int MINW, int LOOK, int LM, int INB = OV_IN_BYTES>
 __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
 {
     const OsParams &p = q.os;
     constexpr int WORKERS = THREADS / 64 - 1, WT = WORKERS * 64, T = WT * K;
-    constexpr int CPT = (OV_IN_BYTES / 16 + WT - 1) / WT; // 16-byte chunks per worker thread
-    __shared__ __attribute__((aligned(16))) uint8_t sin[OV_IN_BYTES + 32]; // reads run up to 19 bytes past a record
-    __shared__ __attribute__((aligned(16))) uint8_t sout[OV_IN_BYTES + 16];
+    constexpr int CPT = (INB / 16 + WT - 1) / WT; // 16-byte chunks per worker thread
+    __shared__ __attribute__((aligned(16))) uint8_t sin[INB + 32]; // reads run up to 19 bytes past a record
+    __shared__ __attribute__((aligned(16))) uint8_t sout[INB + 16];
     __shared__ uint32_t wcnt[2 * WORKERS * OS_MAXP]; // bytes per (wave, dest), two tiles
     __shared__ uint32_t wslot[WORKERS * OS_MAXP];    // first image byte of (wave, dest)
     __shared__ uint32_t dstart2[2 * OS_MAXP];        // first image byte of dest, two tiles
@@ -268,9 +271,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
 
     if (p.finder && blockIdx.x == 0) {
         // streams layout: this workgroup finds the rounds instead of sweeping
-        static_assert(sizeof(FinderLds) <= sizeof(sout), "the finder's tables live in the image buffer");
+        typedef FinderLdsT<T / 64> FL;
+        static_assert(sizeof(FL) <= sizeof(sout), "the finder's tables live in the image buffer");
         FinderSrcV src{q, sin};
-        os_round_finder<FinderSrcV, THREADS / 64, T / 64>(p, P, src, reinterpret_cast<FinderLds *>(sout), tid);
+        os_round_finder<FinderSrcV, THREADS / 64, T / 64>(p, P, src, reinterpret_cast<FL *>(sout), tid);
         return;
     }
 

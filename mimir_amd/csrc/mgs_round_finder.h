@@ -35,12 +35,13 @@ constexpr int FR_MAX_ROWS = 56;            // rows of 64 records in the largest 
 constexpr int FR_MAX_TILE = FR_MAX_ROWS * 64;
 constexpr uint32_t FR_EXIT = 0xFFFFFFFFu;
 
-struct FinderLds {
-    uint32_t rowcnt[FR_MAX_ROWS][OS_MAXP]; // units per (row of the tile, column)
-    uint32_t units[FR_MAX_TILE];           // units of every record of the tile (0: no record)
-    uint8_t dest[FR_MAX_TILE];             // its destination (0xFF: no record)
-    unsigned long long cnt[OS_MAXP];       // units per column of a row's lanes before a cut
-    volatile uint32_t cmd[4];              // [0] tile to examine next, or FR_EXIT
+template <int ROWS> // rows of 64 records in a tile
+struct FinderLdsT {
+    uint32_t rowcnt[ROWS][OS_MAXP];  // units per (row of the tile, column)
+    uint32_t units[ROWS * 64];       // units of every record of the tile (0: no record)
+    uint8_t dest[ROWS * 64];         // its destination (0xFF: no record)
+    unsigned long long cnt[OS_MAXP]; // units per column of a row's lanes before a cut
+    volatile uint32_t cmd[4];        // [0] tile to examine next, or FR_EXIT
 };
 
 // 16-byte records straight from global memory.
@@ -65,7 +66,7 @@ struct FinderSrc16 {
 
 // NW waves in the workgroup, tiles of at most MAXROWS rows of 64 records.
 template <class Src, int NW, int MAXROWS>
-__device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, Src &src, FinderLds *x, int tid)
+__device__ __forceinline__ void os_round_finder(const OsParams &p, uint32_t P, Src &src, FinderLdsT<MAXROWS> *x, int tid)
 {
     constexpr int nw = NW, nthreads = NW * 64, RPW = (MAXROWS + NW - 1) / NW;
     static_assert(MAXROWS <= FR_MAX_ROWS, "the finder's tables hold FR_MAX_ROWS rows");
