@@ -212,7 +212,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # MGS_BENCH_FORCE_DIST=1: take the N > 1 branch with a world of one rank too (on a one-GPU box this is
+    # the only way to execute the RCCL process group, its collectives and the exchange code at all)
+    distributed = world > 1 or os.environ.get("MGS_BENCH_FORCE_DIST") == "1"
     # MGS_BENCH_BACKEND=gloo is the rehearsal mode for boxes with fewer GPUs than
     # ranks: ranks share the devices round-robin and the partitions travel through
     # host memory.  Its numbers say nothing about xGMI and are labelled as such.
