@@ -1346,6 +1346,13 @@ int mgs_get_desc(const mgs_handle *h, mgs_desc *out)
 
 // ---- receive side -----------------------------------------------------------------
 constexpr uint32_t kUnpMaxCuts = 4096;
+// Chunks (one wave each) a stream is cut into by the parse kernels; MGS_PARSE_CHUNKS overrides (A/B timing).
+static uint64_t parse_chunks()
+{
+    static const char *env = getenv("MGS_PARSE_CHUNKS");
+    const long v = env ? atol(env) : 0;
+    return v >= 2048 && v <= 65536 ? (uint64_t) v : (uint64_t) UNP_MAX_CHUNKS;
+}
 constexpr size_t kUnpScratch = 8u << 20; // first allocation; grows with the stream
 
 // Scratch of the blocking parse calls (unpack, tokenize): one buffer per handle.
@@ -1401,7 +1408,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     p.V = (L.val_kind == MGS_VAL_FIXED) ? (uint32_t) L.val_bytes : 0u;
     const uint32_t S = p.V + 2;
     // one wave per chunk, one lane per piece; pieces of at least four 64-byte blocks
-    uint64_t chunk = (nbytes + UNP_MAX_CHUNKS - 1) / UNP_MAX_CHUNKS;
+    uint64_t chunk = (nbytes + parse_chunks() - 1) / parse_chunks();
     chunk = std::max<uint64_t>(16384, (chunk + 4095) / 4096 * 4096);
     p.chunk_bytes = (uint32_t) chunk;
     p.piece_bytes = (uint32_t) (chunk / UNP_PIECES);
@@ -1518,7 +1525,7 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint
     p.nbytes = nbytes;
     // one wave per chunk, one lane per piece; the end of the text (position nbytes) is
     // covered too: it closes an open word
-    uint64_t chunk = (nbytes + 1 + UNP_MAX_CHUNKS - 1) / UNP_MAX_CHUNKS;
+    uint64_t chunk = (nbytes + 1 + parse_chunks() - 1) / parse_chunks();
     chunk = std::max<uint64_t>(16384, (chunk + 4095) / 4096 * 4096);
     p.chunk_bytes = (uint32_t) chunk;
     p.piece_bytes = (uint32_t) (chunk / UNP_PIECES);
