@@ -527,8 +527,25 @@ int mgs_stager_put(mgs_stager *s, const void *key, uint32_t klen,
 uint64_t mgs_stager_pending(const mgs_stager *s);
 int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records,
                     int *drained);
+/* mgs_stager_pack in two halves, for a caller with work of its own while the GPU
+ * packs (the non-blocking shuffler tests its exchanges in flight,
+ * src/nbcollectiveshuffler.h:279-387): _begin enqueues the upload and the pack
+ * kernels (mgs_pack_device_async), _end waits and reports as mgs_stager_pack does.
+ * No other stager call between the two. */
+int mgs_stager_pack_begin(mgs_stager *s);
+int mgs_stager_pack_end(mgs_stager *s, mgs_round *out,
+                        const void **local_records, int *drained);
 int mgs_stager_send_image_host(mgs_stager *s, const void **host_image,
                                const int64_t **send_offset);
+/* The host view copied straight into a buffer of the caller's (nranks*buf_size
+ * bytes, partition d at d*buf_size): the message buffers of the non-blocking
+ * shuffler (src/nbcollectiveshuffler.h:426-449, :222-277).  mgs_host_alloc /
+ * mgs_host_free hand out page-locked memory, which the copy reaches directly (the
+ * reference's buffers come from mem_aligned_malloc, :434-437). */
+int mgs_stager_send_image_to(mgs_stager *s, void *host_dst,
+                             const int64_t **send_offset);
+void *mgs_host_alloc(size_t bytes);
+void mgs_host_free(void *p);
 int mgs_stager_send_image_device(mgs_stager *s, void **d_image,
                                  const int64_t **send_offset);
 int mgs_stager_round_done(mgs_stager *s);

@@ -321,7 +321,9 @@ class GpuShuffler : public Writable<KeyType, ValType> {
             mgs_round r;
             const void *local = NULL;
             int drained = 0;
-            if (mgs_stager_pack(stager, &r, &local, &drained) != MGS_OK) fail(mgs_stager_last_error(stager));
+            if (mgs_stager_pack_begin(stager) != MGS_OK) fail(mgs_stager_last_error(stager));
+            while_packing(); // the GPU packs; the host may look after its exchanges
+            if (mgs_stager_pack_end(stager, &r, &local, &drained) != MGS_OK) fail(mgs_stager_last_error(stager));
             kvcount += r.packed_records;
             if (r.local_bytes > 0) { // out->write at emit time, :135-141
                 begin_source(shuffle_rank);
@@ -339,6 +341,8 @@ class GpuShuffler : public Writable<KeyType, ValType> {
     virtual void begin_source(int src) { (void) src; }
     // Called after every pack; the non-blocking shuffler pushes its exchanges here.
     virtual void progress() {}
+    // Called while a pack runs on the GPU (no stager call is allowed in here).
+    virtual void while_packing() {}
 
     // src/collectiveshuffler.h:587-674
     virtual void exchange_kv()
@@ -529,7 +533,9 @@ class GpuShuffler : public Writable<KeyType, ValType> {
 // of the counts (with the -1 vote) followed, in token order, by a non-blocking
 // all-to-all-v of the bytes (:222-387).  Records are packed on the device into
 // the stager's image as for GpuShuffler; when a round is full its partitions
-// move into the current message buffer and the image is free again.
+// are copied from the GPU straight into the current (page-locked) message
+// buffer and the image is free again.  While the GPU packs a staged batch the
+// exchanges in flight are pushed on (mgs_stager_pack_begin / _end).
 template <typename KeyType, typename ValType>
 class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
     typedef GpuShuffler<KeyType, ValType> Base;
@@ -550,14 +556,13 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
 
     virtual ~NBGpuShuffler()
     {
-        for (size_t i = 0; i < msg.size(); i++) delete msg[i];
+        free_buffers();
     }
 
     virtual int open() // :72-120
     {
         Base::open();
-        for (size_t i = 0; i < msg.size(); i++) delete msg[i];
-        msg.clear();
+        free_buffers();
         cur_idx = 0;
         a2a_token = a2av_token = 0;
         pending_msg = 0;
@@ -578,7 +583,8 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
     enum State { ShuffleMsgStart, ShuffleMsgPending, ShuffleMsgComplete }; // :22-34
 
     struct MsgBuf {
-        std::vector<char> send_buffer, recv_buffer;
+        char *send_buffer; // page-locked: the partitions are copied here straight from the GPU
+        std::vector<char> recv_buffer;
         std::vector<int> send_offset, recv_count, s_displs, r_displs;
         uint64_t token;
         State state;
@@ -590,7 +596,8 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
     {
         MsgBuf *m = new MsgBuf();
         const size_t P = (size_t) this->shuffle_size;
-        m->send_buffer.resize((size_t) this->buf_size * P);
+        m->send_buffer = static_cast<char *>(mgs_host_alloc((size_t) this->buf_size * P));
+        if (m->send_buffer == NULL) this->fail("NBGpuShuffler: no page-locked memory for a send buffer\n");
         m->recv_buffer.resize((size_t) this->buf_size * P);
         m->send_offset.assign(P, 0);
         m->recv_count.assign(P, 0);
@@ -603,7 +610,17 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
         msg.push_back(m);
     }
 
+    void free_buffers()
+    {
+        for (size_t i = 0; i < msg.size(); i++) {
+            mgs_host_free(msg[i]->send_buffer);
+            delete msg[i];
+        }
+        msg.clear();
+    }
+
     virtual void progress() { push_kv_exchange(); } // after every record in the reference, :179
+    virtual void while_packing() { push_kv_exchange(); }
 
     // A round is full (or the stream has ended): its partitions leave the stager's image
     // for the current message buffer and the exchange is started.
@@ -615,19 +632,14 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
 
     int64_t snapshot()
     {
-        const void *image = NULL;
         const int64_t *send_offset = NULL;
-        if (mgs_stager_send_image_host(this->stager, &image, &send_offset) != MGS_OK)
-            this->fail(mgs_stager_last_error(this->stager));
         MsgBuf *m = msg[(size_t) cur_idx];
+        if (mgs_stager_send_image_to(this->stager, m->send_buffer, &send_offset) != MGS_OK)
+            this->fail(mgs_stager_last_error(this->stager));
         int64_t total = 0;
         for (int i = 0; i < this->shuffle_size; i++) {
-            const int64_t so = send_offset[i];
-            if (so > 0)
-                memcpy(m->send_buffer.data() + (size_t) i * (size_t) this->buf_size,
-                       static_cast<const char *>(image) + (size_t) i * (size_t) this->buf_size, (size_t) so);
-            m->send_offset[(size_t) i] = (int) so;
-            total += so;
+            m->send_offset[(size_t) i] = (int) send_offset[i];
+            total += send_offset[i];
         }
         mgs_stager_round_done(this->stager);
         return total;
@@ -700,7 +712,7 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
                         this->send_bytes += (uint64_t) m->send_offset[(size_t) i];
                     }
                     this->recv_bytes += (uint64_t) recvcount;
-                    m->a2av_req = this->comm->ialltoallv_bytes(m->send_buffer.data(), m->send_offset.data(),
+                    m->a2av_req = this->comm->ialltoallv_bytes(m->send_buffer, m->send_offset.data(),
                                                                m->s_displs.data(), m->recv_buffer.data(),
                                                                m->recv_count.data(), m->r_displs.data());
                     m->state = ShuffleMsgPending;

@@ -123,6 +123,11 @@ SYMBOLS = {
     "mgs_stager_send_image_device": (C.c_int, [_VP, C.POINTER(_VP),
                                                C.POINTER(C.POINTER(C.c_int64))]),
     "mgs_stager_round_done": (C.c_int, [_VP]),
+    "mgs_stager_pack_begin": (C.c_int, [_VP]),
+    "mgs_stager_pack_end": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "mgs_stager_send_image_to": (C.c_int, [_VP, _VP, _VP]),
+    "mgs_host_alloc": (_VP, [C.c_size_t]),
+    "mgs_host_free": (None, [_VP]),
     "mgs_stager_window": (C.c_int, [_VP, _VP]),
     "mgs_stager_commit": (C.c_int, [_VP, C.c_int64, C.c_uint64]),
     "mgs_stager_recv_image_device": (C.c_int, [_VP, C.POINTER(_VP)]),

@@ -1353,6 +1353,13 @@ static uint64_t parse_chunks()
     const long v = env ? atol(env) : 0;
     return v >= 2048 && v <= 65536 ? (uint64_t) v : (uint64_t) UNP_MAX_CHUNKS;
 }
+// The same for the tokenizer's text; MGS_TOK_CHUNKS overrides (A/B timing).
+static uint64_t tok_chunks()
+{
+    static const char *env = getenv("MGS_TOK_CHUNKS");
+    const long v = env ? atol(env) : 0;
+    return v >= 1024 && v <= 65536 ? (uint64_t) v : (uint64_t) TOK_CHUNKS;
+}
 constexpr size_t kUnpScratch = 8u << 20; // first allocation; grows with the stream
 
 // Scratch of the blocking parse calls (unpack, tokenize): one buffer per handle.
@@ -1523,16 +1530,16 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint
     memset(&p, 0, sizeof(p));
     p.text = static_cast<const uint8_t *>(d_text);
     p.nbytes = nbytes;
-    // one wave per chunk, one lane per piece; the end of the text (position nbytes) is
-    // covered too: it closes an open word
-    uint64_t chunk = (nbytes + 1 + parse_chunks() - 1) / parse_chunks();
-    chunk = std::max<uint64_t>(16384, (chunk + 4095) / 4096 * 4096);
+    // one wave per chunk; the end of the text (position nbytes) is covered too: it closes an
+    // open word
+    const uint64_t want = tok_chunks();
+    uint64_t chunk = (nbytes + 1 + want - 1) / want;
+    chunk = (chunk + 4 * TOKS_STEP - 1) / (4 * TOKS_STEP) * (4 * TOKS_STEP); // the kernels take four steps per trip
     p.chunk_bytes = (uint32_t) chunk;
-    p.piece_bytes = (uint32_t) (chunk / UNP_PIECES);
     p.nchunks = (uint32_t) ((nbytes + 1 + chunk - 1) / chunk);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t need = up(2 * sizeof(uint64_t)) + up((size_t) p.nchunks * 3 * 64 * sizeof(uint32_t))
-                        + up((size_t) p.nchunks * 3 * sizeof(uint32_t)) + up((size_t) p.nchunks * 3 * sizeof(uint64_t));
+    const size_t need = up(2 * sizeof(uint64_t)) + up((size_t) p.nchunks * 3 * sizeof(uint32_t))
+                        + up((size_t) p.nchunks * 3 * sizeof(uint64_t));
     if (h->pending) { // the control block and the scratch are shared with the pack call in flight
         h->err = "mgs_tokenize_device: a pack call is in flight on this handle (call mgs_pack_result first)";
         return MGS_ERR_STATE;
@@ -1541,7 +1548,6 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint
     uint8_t *q = h->d_unp;
     p.result = reinterpret_cast<uint64_t *>(q);    q += up(2 * sizeof(uint64_t));
     p.chunk_x = reinterpret_cast<uint64_t *>(q);   q += up((size_t) p.nchunks * 3 * sizeof(uint64_t));
-    p.piece_x = reinterpret_cast<uint32_t *>(q);   q += up((size_t) p.nchunks * 3 * 64 * sizeof(uint32_t));
     p.chunk_tot = reinterpret_cast<uint32_t *>(q); q += up((size_t) p.nchunks * 3 * sizeof(uint32_t));
     p.out = static_cast<uint8_t *>(d_records);
     p.out_cap = records_capacity;
@@ -1551,11 +1557,14 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint
     p.ctrl = h->d_ctrl;
 
     MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
-    const size_t lds_count = 128 * sizeof(uint32_t);
-    const size_t lds_emit = 128 * sizeof(uint32_t) + 2 * 64 * TOK_ROW_PITCH + 64 * UNP_SLOT_PITCH * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_tok_count, dim3(p.nchunks), dim3(64), lds_count, stream, p);
-    hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(64), 0, stream, p);
-    hipLaunchKernelGGL(k_tok_emit, dim3(p.nchunks), dim3(64), lds_emit, stream, p);
+    if (nbytes < 16) { // the streaming kernels fetch 16 bytes at a time
+        hipLaunchKernelGGL(k_tok_tiny, dim3(1), dim3(64), 0, stream, p);
+    }
+    else {
+        hipLaunchKernelGGL(k_tok_count, dim3(p.nchunks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(k_tok_stream, dim3(p.nchunks), dim3(64), 0, stream, p);
+    }
     MGS_HIP(h, hipGetLastError());
     MGS_HIP(h, hipMemcpyAsync(h->h_unp, p.result, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     MGS_HIP(h, hipMemcpyAsync(&h->h_ctrl->head.error, &h->d_ctrl->head.error, sizeof(int32_t),

@@ -41,6 +41,7 @@ struct mgs_stager {
     uint64_t nrec = 0;
     uint64_t cursor = 0; // first staged record not packed yet
     bool uploaded = false;
+    bool in_flight = false; // mgs_stager_pack_begin without its mgs_stager_pack_end
     int64_t send_offset[MGS_MAX_RANKS];
     // combiner mode (mgs_stager_set_combine): the current round's records stay staged
     int combine_op = -1;
@@ -345,22 +346,19 @@ int mgs_stager_commit(mgs_stager *s, int64_t used, uint64_t nrec)
 // record that did not fit (src/collectiveshuffler.h:148-160).
 // *local_records points at out->local_bytes bytes of wire-form records whose
 // destination is this rank, in emit order (valid until the next call).
-int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records, int *drained)
+//
+// In two halves for a caller that has other work while the GPU packs (the
+// non-blocking shuffler tests its exchanges in flight,
+// src/nbcollectiveshuffler.h:279-387): mgs_stager_pack_begin enqueues the upload
+// and the pack kernels and returns, mgs_stager_pack_end waits for them.
+int mgs_stager_pack_begin(mgs_stager *s)
 {
-    if (!s || !out || !drained) return MGS_ERR_ARG;
-    memset(out, 0, sizeof(*out));
-    if (local_records) *local_records = s->h_local;
-    if (s->combine_op >= 0) return stager_pack_combine(s, out, drained);
-    if (s->cursor >= s->nrec) {
-        for (int b = 0; b < s->desc.nranks; b++) out->send_offset[b] = s->send_offset[b];
-        out->next = s->cursor;
-        s->nrec = 0;
-        s->used = 0;
-        s->cursor = 0;
-        s->uploaded = false;
-        *drained = 1;
-        return MGS_OK;
+    if (!s) return MGS_ERR_ARG;
+    if (s->in_flight) {
+        s->err = "mgs_stager_pack_begin: a pack is in flight already";
+        return MGS_ERR_STATE;
     }
+    if (s->combine_op >= 0 || s->cursor >= s->nrec) return MGS_OK; // nothing to enqueue: pack_end does it all
     int prev = -1;
     (void) hipGetDevice(&prev);
     struct Restore {
@@ -375,9 +373,46 @@ int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records, i
                                       hipMemcpyHostToDevice, s->stream));
         s->uploaded = true;
     }
-    int rc = mgs_pack_device(s->h, s->d_stage, s->fixed ? nullptr : s->d_off, s->nrec, s->cursor,
-                             s->send_offset, s->d_image, s->desc.rank >= 0 ? s->d_local : nullptr,
-                             s->cap, nullptr, MGS_ALGO_AUTO, s->stream, out);
+    const int rc = mgs_pack_device_async(s->h, s->d_stage, s->fixed ? nullptr : s->d_off, s->nrec, s->cursor,
+                                         s->send_offset, s->d_image, s->desc.rank >= 0 ? s->d_local : nullptr,
+                                         s->cap, nullptr, MGS_ALGO_AUTO, s->stream);
+    if (rc != MGS_OK) {
+        s->err = mgs_last_error(s->h);
+        return rc;
+    }
+    s->in_flight = true;
+    return MGS_OK;
+}
+
+int mgs_stager_pack_end(mgs_stager *s, mgs_round *out, const void **local_records, int *drained)
+{
+    if (!s || !out || !drained) return MGS_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    if (local_records) *local_records = s->h_local;
+    if (s->combine_op >= 0) return stager_pack_combine(s, out, drained);
+    if (!s->in_flight) {
+        if (s->cursor < s->nrec) {
+            s->err = "mgs_stager_pack_end: no pack in flight (call mgs_stager_pack_begin)";
+            return MGS_ERR_STATE;
+        }
+        for (int b = 0; b < s->desc.nranks; b++) out->send_offset[b] = s->send_offset[b];
+        out->next = s->cursor;
+        s->nrec = 0;
+        s->used = 0;
+        s->cursor = 0;
+        s->uploaded = false;
+        *drained = 1;
+        return MGS_OK;
+    }
+    s->in_flight = false;
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    struct Restore {
+        int p;
+        ~Restore() { if (p >= 0) (void) hipSetDevice(p); }
+    } restore{prev};
+    STG_HIP(s, hipSetDevice(s->desc.device));
+    const int rc = mgs_pack_result(s->h, out);
     if (rc != MGS_OK) {
         s->err = mgs_last_error(s->h);
         return rc;
@@ -412,6 +447,14 @@ int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records, i
     return MGS_OK;
 }
 
+int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records, int *drained)
+{
+    if (!s || !out || !drained) return MGS_ERR_ARG;
+    const int rc = mgs_stager_pack_begin(s);
+    if (rc != MGS_OK) return rc;
+    return mgs_stager_pack_end(s, out, local_records, drained);
+}
+
 // The round's send image.  Host view: the valid bytes of every partition are
 // copied to a pinned mirror with the reference's layout (partition d at
 // d*buf_size, src/collectiveshuffler.h:635) -- what MPI_Alltoallv reads.
@@ -437,6 +480,46 @@ int mgs_stager_send_image_host(mgs_stager *s, const void **host_image, const int
     *host_image = s->h_image;
     *send_offset = s->send_offset;
     return MGS_OK;
+}
+
+// The same copy into a buffer of the caller's (a message buffer of the non-blocking
+// shuffler, src/nbcollectiveshuffler.h:426-449: nranks * buf_size bytes): the partitions
+// go where the exchange reads them, without a stop in the stager's own mirror.  Memory from
+// mgs_host_alloc is copied to directly; any other host memory works, more slowly.
+int mgs_stager_send_image_to(mgs_stager *s, void *host_dst, const int64_t **send_offset)
+{
+    if (!s || !host_dst || !send_offset) return MGS_ERR_ARG;
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    (void) hipSetDevice(s->desc.device);
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < s->desc.nranks && e == hipSuccess; b++) {
+        if (s->send_offset[b] > 0)
+            e = hipMemcpyAsync(static_cast<uint8_t *>(host_dst) + (size_t) b * s->desc.buf_size,
+                               s->d_image + (size_t) b * s->desc.buf_size,
+                               (size_t) s->send_offset[b], hipMemcpyDeviceToHost, s->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (prev >= 0) (void) hipSetDevice(prev);
+    if (e != hipSuccess) {
+        s->err = sfmt("send image copy failed: %s", hipGetErrorString(e));
+        return MGS_ERR_HIP;
+    }
+    *send_offset = s->send_offset;
+    return MGS_OK;
+}
+
+// Page-locked host memory for buffers the library copies to or from.
+void *mgs_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void mgs_host_free(void *p)
+{
+    if (p) (void) hipHostFree(p);
 }
 
 // Device view, for an exchange that reads GPU memory (RCCL, GPU-aware MPI).

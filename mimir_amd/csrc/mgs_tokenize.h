@@ -13,24 +13,25 @@
 // A word byte goes to the output at (kept word bytes before it) + 9 * (kept
 // words closed before it), so all that is needed are three prefix sums over the
 // text: kept word bytes, words closed, words started (the record's index).  The
-// text is cut like the receive stream of mgs_unpack.h: chunks, one wave each, 64
-// pieces per chunk, one lane each; a lane walks its piece 64 bytes at a time on
-// a 64-bit mask of word bytes.
+// text is cut into chunks, one wave each; a wave streams through its chunk 1 KiB
+// at a time, lane = 16 consecutive bytes: one coalesced 16-byte load per lane, a
+// 16-bit mask of word bytes, and the three counts of a step are one packed wave
+// scan.
 //
-//   k_tok_count  per piece: kept word bytes, words closed, words started;
-//                exclusive sums over the pieces of a chunk, chunk totals.
-//   k_tok_scan   one wave: exclusive sums over the chunks, capacity checks.
-//   k_tok_emit   every lane walks its piece again and streams its output: word
-//                bytes as they come, NUL + value where a word closes; the record
-//                offsets where words start.  Both streams are collected in LDS
-//                in 64-byte groups of the output and leave with 16-byte stores.
+//   k_tok_count   per chunk: kept word bytes, words closed, words started.
+//   k_tok_scan    one workgroup: exclusive sums over the chunks, capacity checks.
+//   k_tok_stream  the same walk again; every lane writes its runs of word bytes,
+//                 the NUL + value after a word that closes in its bytes and the
+//                 offsets of the words that start there into an LDS image of the
+//                 step's output, which leaves with aligned 16-byte stores.
 //
-// The 1024-byte rule is the only thing that needs more than the byte before a
-// block: whether a word is dropped must be known where it starts.  A word that
-// starts and closes inside one block or the next is short.  Only where a word is
-// open at the end of a block and the whole next block consists of word bytes
-// (or where a piece begins inside a word) is its length measured by walking the
-// text itself (tok_word_is_long) -- the same answer in whichever lane asks.
+// The 1024-byte rule needs the length of a word where it starts.  A word that
+// starts at byte o of a step and runs to the step's end is 1024 - o bytes there
+// plus the leading run of word bytes of the next step, whose masks are at hand
+// one step ahead; if that whole step is word bytes the word is long in any
+// case.  So a wave carries two flags from step to step -- a word is open, it is
+// being dropped -- and measures a word on the text itself (tok_word_is_long)
+// only where its chunk begins inside one.
 #ifndef MGS_TOKENIZE_H
 #define MGS_TOKENIZE_H
 
@@ -39,16 +40,17 @@
 namespace mgs {
 
 constexpr uint32_t TOK_MAX_WORD = 1024; // strlen(word) < 1024, examples/wordcount.cpp:72
-constexpr int TOK_ROW_PITCH = 80;       // bytes per lane in the LDS copies of a block / an output group
+constexpr int TOK_CHUNKS = 4096;        // chunks (one wave each) a large text is cut into: four waves per SIMD
+constexpr int TOKS_STEP = 1024;         // text bytes per step of a wave
+constexpr int TOKS_OBUF = 16 + 9 * 512 + 1024 + 32; // output of a step at most: every byte kept, a word closed every other byte
+constexpr int TOKS_RBUF = 4 + 512 + 8;              // record offsets of a step
 
 struct TokParams {
     const uint8_t *text;
     uint64_t nbytes;
-    uint32_t chunk_bytes; // 64 pieces
-    uint32_t piece_bytes; // multiple of 64
+    uint32_t chunk_bytes; // multiple of 4 * TOKS_STEP
     uint32_t nchunks;     // covers nbytes + 1 bytes: the end of the text closes an open word
-    uint32_t *piece_x;    // [nchunks][3][64] kept word bytes / closed / started before the piece, in its chunk
-    uint32_t *chunk_tot;  // [nchunks][3]
+    uint32_t *chunk_tot;  // [nchunks][3] kept word bytes / words closed / words started in the chunk
     uint64_t *chunk_x;    // [nchunks][3] the same before the chunk, in the text
     uint8_t *out;         // records
     uint64_t out_cap;
@@ -73,15 +75,13 @@ __device__ __noinline__ bool tok_word_is_long(const TokParams &p, uint64_t at)
     return len >= TOK_MAX_WORD;
 }
 
-// The lane's 16 bytes of text at `at` (see unp_load16) and their word-byte mask:
-// bit i set = text[at + i] is a word byte; bytes past the end are not.
+// The lane's 16 bytes of text at `at` and their word-byte mask: bit i set = text[at + i]
+// is a word byte; bytes past the end are not.  The text has at least 16 bytes (shorter ones
+// go through k_tok_tiny): a lane that sticks out of it fetches the text's last 16 bytes.
+// Nothing but this one load on purpose -- a second path with loads of its own would make
+// every wait for memory in the callers' loops a wait for all of it.
 __device__ __forceinline__ uint4 tok_load16(const TokParams &p, uint64_t at)
 {
-    if (p.nbytes < 16) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        for (uint32_t i = 0; i < 16 && at + i < p.nbytes; i++) w[i >> 2] |= (uint32_t) p.text[at + i] << (8 * (i & 3));
-        return make_uint4(w[0], w[1], w[2], w[3]);
-    }
     const uint64_t a = min(at, p.nbytes - 16);
     const UnpU128 v = *reinterpret_cast<const UnpU128 *>(p.text + a);
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -96,7 +96,6 @@ __device__ __forceinline__ uint32_t tok_m16(const TokParams &p, uint64_t at, con
     };
     const uint32_t m = ~(delim(v.x) | (delim(v.y) << 4) | (delim(v.z) << 8) | (delim(v.w) << 12)) & 0xFFFFu;
     if (at >= p.nbytes) return 0;
-    if (p.nbytes < 16) return m; // tok_load16 left zeros past the end
     if (at + 16 > p.nbytes) return m >> (uint32_t) (at - (p.nbytes - 16));
     return m;
 }
@@ -105,7 +104,7 @@ __device__ __forceinline__ uint32_t tok_m16(const TokParams &p, uint64_t at, con
 // fetched 16 bytes back from its end).
 __device__ __forceinline__ uint4 tok_in_place(const TokParams &p, uint64_t at, const uint4 &v)
 {
-    if (p.nbytes < 16 || at + 16 <= p.nbytes || at >= p.nbytes) return v;
+    if (at + 16 <= p.nbytes || at >= p.nbytes) return v;
     const uint32_t sh = (uint32_t) (at - (p.nbytes - 16)); // 1..15 bytes
     const uint32_t w[8] = {v.x, v.y, v.z, v.w, 0, 0, 0, 0};
     uint32_t r[4];
@@ -124,92 +123,47 @@ __device__ __forceinline__ uint4 tok_in_place(const TokParams &p, uint64_t at, c
     return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
-__device__ __forceinline__ uint64_t tok_row_at(const TokParams &p, uint64_t c0, uint32_t b, int j, int lane)
+// A text of fewer than 16 bytes: one lane does everything.
+__global__ __launch_bounds__(64) void k_tok_tiny(TokParams p)
 {
-    return c0 + (uint64_t) (16 * j + (lane >> 2)) * p.piece_bytes + 64u * b + 16u * (uint32_t) (lane & 3);
-}
-
-__device__ __forceinline__ void tok_rows_load(const TokParams &p, uint64_t c0, uint32_t b, int lane, UnpRows &r)
-{
-#pragma unroll
-    for (int j = 0; j < 4; j++) r.raw[j] = tok_load16(p, tok_row_at(p, c0, b, j, lane));
-}
-
-// Word masks of the rows just loaded -> every lane's own 64-bit mask (through
-// LDS).  With `bytes`, the bytes of that (other) block b_bytes are handed to
-// their lanes on the way: row r at rows_lds + r * TOK_ROW_PITCH.
-__device__ __forceinline__ uint64_t tok_rows_mask(const TokParams &p, uint64_t c0, uint32_t b, int lane,
-                                                  const UnpRows &r, uint16_t *smask,
-                                                  const UnpRows *bytes = nullptr, uint32_t b_bytes = 0,
-                                                  uint8_t *rows_lds = nullptr)
-{
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        smask[64 * j + lane] = (uint16_t) tok_m16(p, tok_row_at(p, c0, b, j, lane), r.raw[j]);
-        if (bytes)
-            *reinterpret_cast<uint4 *>(rows_lds + (16 * j + (lane >> 2)) * TOK_ROW_PITCH + 16 * (lane & 3)) =
-                tok_in_place(p, tok_row_at(p, c0, b_bytes, j, lane), bytes->raw[j]);
+    if (threadIdx.x != 0) return;
+    uint64_t words = 0, bytes = 0;
+    for (uint64_t i = 0; i < p.nbytes; i++) {
+        if (!tok_is_word_byte(p.text[i])) continue;
+        bytes++;
+        if (i + 1 == p.nbytes || !tok_is_word_byte(p.text[i + 1])) words++;
     }
-    __syncthreads();
-    const uint64_t w = reinterpret_cast<const uint64_t *>(smask)[lane];
-    __syncthreads();
-    return w;
+    bytes += 9 * words;
+    p.result[0] = words;
+    p.result[1] = bytes;
+    if (bytes > p.out_cap || words + 1 > p.rec_cap) {
+        raise_error(p.ctrl, MGS_ERR_ARG);
+        return;
+    }
+    uint64_t v = 0, n = 0;
+    bool open = false;
+    for (uint64_t i = 0; i <= p.nbytes; i++) {
+        const bool w = i < p.nbytes && tok_is_word_byte(p.text[i]);
+        if (w) {
+            if (!open) p.rec_off[n++] = (uint32_t) v;
+            p.out[v++] = p.text[i];
+        }
+        else if (open) { // NUL + value (src/serializer.h:63-83, :157-168)
+            p.out[v++] = 0;
+            for (int k = 0; k < 8; k++) p.out[v++] = (uint8_t) (p.value >> (8 * k));
+        }
+        open = w;
+    }
+    p.rec_off[n] = (uint32_t) v;
 }
 
-// Parser state of a lane between blocks.
+// State of the walk between steps.
 struct TokState {
-    bool open;     // the byte before the block belongs to a word
+    bool open;     // the byte before the step belongs to a word
     bool dropping; // ... that is being dropped
 };
 
-// What a block holds, given the state it is entered in.
-struct TokBlock {
-    uint64_t keep;   // word bytes of kept words
-    uint64_t starts; // first bytes of kept words
-    uint64_t closes; // positions right after the last byte of a kept word
-};
-
-// pos0 = text position of the block's first byte; W, Wnext = word masks of the
-// block and the one after it.
-__device__ __forceinline__ TokBlock tok_block(const TokParams &p, uint64_t W, uint64_t Wnext, uint64_t pos0,
-                                              TokState &st)
-{
-    const uint64_t prev = (W << 1) | (uint64_t) st.open;
-    TokBlock r;
-    r.keep = W;
-    r.starts = W & ~prev;
-    r.closes = ~W & prev;
-    if (st.open && st.dropping) { // the word the block is entered in is not kept
-        const uint32_t lead = (~W == 0) ? 64u : (uint32_t) __ffsll((unsigned long long) ~W) - 1u;
-        const uint64_t m = lead >= 64 ? ~0ull : ((1ull << lead) - 1ull);
-        r.keep &= ~m;
-        if (lead < 64) r.closes &= ~(1ull << lead);
-    }
-    bool drop_last = st.open && st.dropping && ~W == 0;
-    if ((W >> 63) && ~W != 0) { // a word is open at the end of the block
-        const uint32_t ts = 64u - (uint32_t) __clzll((long long) ~W); // its first byte in this block
-        const bool starts_here = ts > 0 || !st.open;
-        if (starts_here) {
-            drop_last = (~Wnext == 0) && tok_word_is_long(p, pos0 + ts);
-            if (drop_last) {
-                r.keep &= (1ull << ts) - 1ull;
-                r.starts &= ~(1ull << ts);
-            }
-        }
-    }
-    else if ((W >> 63) && !st.open) { // the whole block is the beginning of a word
-        drop_last = (~Wnext == 0) && tok_word_is_long(p, pos0);
-        if (drop_last) {
-            r.keep = 0;
-            r.starts = 0;
-        }
-    }
-    st.open = (W >> 63) != 0;
-    st.dropping = st.open && drop_last;
-    return r;
-}
-
-// State at the beginning of a piece.
+// State at the beginning of a chunk.
 __device__ __forceinline__ TokState tok_enter(const TokParams &p, uint64_t a0)
 {
     TokState st;
@@ -218,38 +172,111 @@ __device__ __forceinline__ TokState tok_enter(const TokParams &p, uint64_t a0)
     return st;
 }
 
-// Dynamic LDS: 256 block masks.
+// leading run of word bytes of a step, from the lanes' 16-bit masks (0..1024)
+__device__ __forceinline__ uint32_t toks_lead(uint32_t m)
+{
+    const uint64_t notfull = __ballot(m != 0xFFFFu);
+    if (!notfull) return TOKS_STEP;
+    const int l = __ffsll((unsigned long long) notfull) - 1;
+    const uint32_t ml = (uint32_t) __builtin_amdgcn_readlane((int) m, l);
+    return 16u * (uint32_t) l + (uint32_t) __builtin_ctz(~ml | 0x10000u);
+}
+
+// What a lane's 16 bytes hold, given the state the step is entered in.
+struct ToksLane {
+    uint32_t keep;   // word bytes of kept words
+    uint32_t starts; // first bytes of kept words
+    uint32_t closes; // positions right after the last byte of a kept word
+};
+
+// m, m_n = the lanes' word masks of this step and the next; st: in = before the step,
+// out = after it.
+__device__ __forceinline__ ToksLane toks_step(uint32_t m, uint32_t m_n, TokState &st, int lane)
+{
+    const bool open_in = st.open, dropping_in = st.dropping;
+    // the byte before the lane's 16 (a word that ends with a lane's last byte closes in the next lane)
+    const uint32_t up = (uint32_t) __shfl_up((int) m, 1);
+    const uint32_t pb = lane ? (up >> 15) & 1u : (open_in ? 1u : 0u);
+    // the step's words that are dropped: the one it is entered in, the one open at its end
+    const uint32_t lead = toks_lead(m);
+    const bool open_out = (((uint32_t) __builtin_amdgcn_readlane((int) m, 63) >> 15) & 1u) != 0;
+    uint32_t drop_from = TOKS_STEP; // bytes from here on belong to a dropped word
+    bool dropping_out = false;
+    if (open_out) {
+        if (lead == TOKS_STEP) {
+            dropping_out = open_in ? dropping_in : true; // a word that fills a whole step is long
+            if (dropping_out) drop_from = 0;
+        }
+        else {
+            // first byte of the trailing run
+            const uint64_t notfull = __ballot(m != 0xFFFFu);
+            const int l = 63 - __builtin_clzll((unsigned long long) notfull);
+            const uint32_t ml = (uint32_t) __builtin_amdgcn_readlane((int) m, l);
+            const uint32_t o = 16u * (uint32_t) l + (32u - (uint32_t) __builtin_clz(~ml & 0xFFFFu));
+            dropping_out = toks_lead(m_n) >= o; // 1024 - o bytes here + the next step's leading run >= 1024
+            if (dropping_out) drop_from = o;
+        }
+    }
+    const bool drop_in = open_in && dropping_in; // the step's first `lead` bytes belong to a dropped word
+    const uint32_t prevm = ((m << 1) | pb) & 0xFFFFu;
+    ToksLane r;
+    r.keep = m;
+    r.starts = m & ~prevm;
+    r.closes = ~m & prevm & 0xFFFFu;
+    const uint32_t b0 = 16u * (uint32_t) lane; // the lane's first byte in the step
+    if (drop_in && lead > b0) {
+        const uint32_t k = lead - b0; // the lane's first k bytes are dropped (k may pass 16)
+        const uint32_t mk = k >= 16 ? 0xFFFFu : ((1u << k) - 1u);
+        r.keep &= ~mk;
+        if (k < 16) r.closes &= ~(1u << k); // the dropped word's end is no record's end
+    }
+    else if (drop_in && lead == b0) {
+        r.closes &= ~1u;
+    }
+    if (drop_from < b0 + 16u) {
+        const uint32_t k = drop_from > b0 ? drop_from - b0 : 0u;
+        const uint32_t mk = ~((1u << k) - 1u) & 0xFFFFu;
+        r.keep &= ~mk;
+        r.starts &= ~mk;
+    }
+    st.open = open_out;
+    st.dropping = dropping_out;
+    return r;
+}
+
 __global__ __launch_bounds__(64) void k_tok_count(TokParams p)
 {
-    extern __shared__ uint32_t tok_lds[];
-    uint16_t *smask = reinterpret_cast<uint16_t *>(tok_lds);
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x;
     const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
-    const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
-    const uint32_t nb = p.piece_bytes / 64;
-    TokState st = tok_enter(p, a0);
+    const uint32_t nsteps = p.chunk_bytes / TOKS_STEP;
+    auto at_of = [&](uint32_t s) { return c0 + (uint64_t) s * TOKS_STEP + 16u * (uint32_t) lane; };
+    TokState st = tok_enter(p, c0);
     uint32_t nbytes = 0, nclose = 0, nstart = 0;
-    UnpRows rows;
-    tok_rows_load(p, c0, 0, lane, rows);
-    uint64_t W = tok_rows_mask(p, c0, 0, lane, rows, smask);
-    tok_rows_load(p, c0, 1, lane, rows);
-    for (uint32_t b = 0; b < nb; b++) {
-        const UnpRows nxt = rows;
-        if (b + 2 <= nb) tok_rows_load(p, c0, b + 2, lane, rows); // in flight during the walk
-        const uint64_t Wnext = tok_rows_mask(p, c0, b + 1, lane, nxt, smask);
-        const TokBlock blk = tok_block(p, W, Wnext, a0 + 64u * b, st);
-        nbytes += (uint32_t) __popcll(blk.keep);
-        nclose += (uint32_t) __popcll(blk.closes);
-        nstart += (uint32_t) __popcll(blk.starts);
-        W = Wnext;
+    // Three steps' bytes in flight in a ring of four registers (a ring of eight was timed: no
+    // faster, the kernel is bound by its vector instructions, not by the loads).  The loop is
+    // unrolled by the ring size so that no loaded value is moved (a move would wait for its
+    // load); a step's mask is made when it is next in line.
+    uint4 R[4];
+    R[0] = tok_load16(p, at_of(0));
+#pragma unroll
+    for (int i = 1; i < 4; i++) R[i] = tok_load16(p, at_of((uint32_t) i));
+    uint32_t m = tok_m16(p, at_of(0), R[0]);
+    for (uint32_t s0 = 0; s0 < nsteps; s0 += 4) { // chunk_bytes is a multiple of 4 steps
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t s = s0 + (uint32_t) i;
+            R[i] = tok_load16(p, at_of(s + 4)); // past the chunk: the next chunk's bytes, or nothing
+            const uint32_t m_n = tok_m16(p, at_of(s + 1), R[(i + 1) & 3]);
+            const ToksLane x = toks_step(m, m_n, st, lane);
+            nbytes += (uint32_t) __popc(x.keep);
+            nclose += (uint32_t) __popc(x.closes);
+            nstart += (uint32_t) __popc(x.starts);
+            m = m_n;
+        }
     }
     const uint32_t ib = wave_incl_scan_u32(nbytes, lane), ic = wave_incl_scan_u32(nclose, lane),
                    is = wave_incl_scan_u32(nstart, lane);
-    uint32_t *px = p.piece_x + (uint64_t) c * 3 * 64;
-    px[lane] = ib - nbytes;
-    px[64 + lane] = ic - nclose;
-    px[128 + lane] = is - nstart;
     if (lane == 63) {
         p.chunk_tot[3 * c] = ib;
         p.chunk_tot[3 * c + 1] = ic;
@@ -257,176 +284,232 @@ __global__ __launch_bounds__(64) void k_tok_count(TokParams p)
     }
 }
 
-__global__ __launch_bounds__(64) void k_tok_scan(TokParams p)
+// One workgroup: thread t owns a run of consecutive chunks.
+__global__ __launch_bounds__(1024) void k_tok_scan(TokParams p)
 {
-    const int lane = threadIdx.x;
-    uint64_t base[3] = {0, 0, 0};
-    for (uint32_t c0 = 0; c0 < p.nchunks; c0 += 64) {
-        const uint32_t c = c0 + lane;
+    __shared__ uint64_t sh[3][1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (p.nchunks + 1023u) / 1024u;
+    const uint32_t lo = min(t * per, p.nchunks), hi = min(lo + per, p.nchunks);
+    const uint32_t *__restrict__ tot = p.chunk_tot;
+    uint64_t *__restrict__ before = p.chunk_x;
+    // a thread's chunks eight at a time, so that the loads of a batch are in flight together
+    constexpr uint32_t TB = 8;
+    uint64_t sum[3] = {0, 0, 0};
+    for (uint32_t c = lo; c < hi; c += TB) {
+        uint32_t v[TB][3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t v = c < p.nchunks ? p.chunk_tot[3 * c + k] : 0u; // a chunk is at most 2^21 bytes: sums of 64 fit
-            const uint32_t incl = wave_incl_scan_u32(v, lane);
-            if (c < p.nchunks) p.chunk_x[3 * (uint64_t) c + k] = base[k] + (incl - v);
-            base[k] += (uint32_t) __shfl((int) incl, 63);
+        for (uint32_t i = 0; i < TB; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[i][k] = c + i < hi ? tot[3 * (c + i) + k] : 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < TB; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) sum[k] += v[i][k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) sh[k][t] = sum[k];
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint64_t add[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) add[k] = t >= d ? sh[k][t - d] : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; k++) sh[k][t] += add[k];
+        __syncthreads();
+    }
+    uint64_t base[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) base[k] = sh[k][t] - sum[k];
+    for (uint32_t c = lo; c < hi; c += TB) {
+        uint32_t v[TB][3];
+#pragma unroll
+        for (uint32_t i = 0; i < TB; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[i][k] = c + i < hi ? tot[3 * (c + i) + k] : 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < TB; i++) {
+            if (c + i < hi) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    before[3 * (uint64_t) (c + i) + k] = base[k];
+                    base[k] += v[i][k];
+                }
+            }
         }
     }
-    if (lane == 0) {
-        const uint64_t words = base[1], bytes = base[0] + 9 * base[1];
+    if (t == 1023) {
+        const uint64_t words = sh[1][1023], bytes = sh[0][1023] + 9 * sh[1][1023];
         p.result[0] = words;
         p.result[1] = bytes;
         // every kept word starts once and closes once
-        if (base[1] != base[2]) raise_error(p.ctrl, MGS_ERR_STATE);
+        if (sh[1][1023] != sh[2][1023]) raise_error(p.ctrl, MGS_ERR_STATE);
         else if (bytes > p.out_cap || words + 1 > p.rec_cap || bytes >= (1ull << 32)) raise_error(p.ctrl, MGS_ERR_ARG);
         else p.rec_off[words] = (uint32_t) bytes;
     }
 }
 
-// A lane's output bytes.  They are gathered eight at a time in a register and
-// collected in LDS in groups of 64 that are 64-byte groups of the output
-// (counted from a 16-byte boundary at or below `out`); a complete group leaves
-// with four 16-byte stores, the bytes of a group shared with a neighbour one by
-// one.
-struct TokSink {
-    uint8_t *slot;
-    uint8_t *out;     // moved back to a 16-byte boundary
-    uint64_t v;       // next byte to write, counted from `out`
-    uint64_t v_first; // first byte of this lane
-    uint64_t acc;     // the (v & 7) bytes of the current 8-byte unit that are there already
+struct __attribute__((packed)) TokU16 { uint16_t v; };
+struct __attribute__((packed)) TokU32 { uint32_t v; };
+struct __attribute__((packed)) TokU64 { unsigned long long v; };
 
-    // the k low bytes of x (1 <= k <= 8, the bytes above them zero)
-    __device__ __forceinline__ void append(uint64_t x, uint32_t k)
-    {
-        const uint32_t fill = (uint32_t) v & 7u;
-        acc |= x << (8 * fill);
-        if (fill + k >= 8) {
-            const uint32_t unit = (uint32_t) v & 56u;
-            const uint64_t g = v & ~(uint64_t) 63;
-            *reinterpret_cast<uint64_t *>(slot + unit) = acc;
-            acc = fill ? x >> (8 * (8 - fill)) : 0ull;
-            v += k;
-            if (unit == 56u) flush_group(g); // the group's last unit
-        }
-        else {
-            v += k;
-        }
-    }
-    __device__ __forceinline__ void flush_group(uint64_t g)
-    {
-        if (g >= v_first) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(slot);
-            uint4 *dst = reinterpret_cast<uint4 *>(out + g);
-#pragma unroll
-            for (int i = 0; i < 4; i++) dst[i] = src[i];
-        }
-        else {
-            store_part(g, (uint32_t) v_first & 63u, 64u);
-        }
-    }
-    // bytes [lo, hi) of the group at g: single bytes up to an 8-byte boundary, 8-byte
-    // units, single bytes again
-    __device__ __forceinline__ void store_part(uint64_t g, uint32_t lo, uint32_t hi)
-    {
-        uint32_t e = lo;
-        for (; e < hi && (e & 7u); e++) out[g + e] = slot[e];
-        for (; e + 8 <= hi; e += 8)
-            *reinterpret_cast<uint64_t *>(out + g + e) = *reinterpret_cast<const uint64_t *>(slot + e);
-        for (; e < hi; e++) out[g + e] = slot[e];
-    }
-    __device__ __forceinline__ void finish()
-    {
-        if ((uint32_t) v & 7u) *reinterpret_cast<uint64_t *>(slot + ((uint32_t) v & 56u)) = acc;
-        const uint64_t g = v & ~(uint64_t) 63;
-        const uint64_t lo = max(g, v_first);
-        if (lo < v) store_part(g, (uint32_t) (lo - g), (uint32_t) (v - g));
-    }
-};
-
-// Eight bytes of a lane's block in LDS from byte `off` on (row: 8-byte aligned;
-// bytes up to off + 15 are read).
-__device__ __forceinline__ uint64_t tok_row_get8(const uint8_t *row, uint32_t off)
+// len (1..8) low bytes of x to LDS at any alignment
+__device__ __forceinline__ void toks_put(uint8_t *o, unsigned long long x, uint32_t len)
 {
-    const uint64_t *q = reinterpret_cast<const uint64_t *>(row + (off & ~7u));
-    const uint64_t lo = q[0], hi = q[1];
-    const uint32_t sh = 8u * (off & 7u);
-    return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+    if (len >= 8) {
+        reinterpret_cast<TokU64 *>(o)->v = x;
+        return;
+    }
+    if (len & 4u) {
+        reinterpret_cast<TokU32 *>(o)->v = (uint32_t) x;
+        x >>= 32;
+        o += 4;
+    }
+    if (len & 2u) {
+        reinterpret_cast<TokU16 *>(o)->v = (uint16_t) x;
+        x >>= 16;
+        o += 2;
+    }
+    if (len & 1u) *o = (uint8_t) x;
 }
 
-// Dynamic LDS: 256 block masks, the 64 lanes' blocks, the lanes' output groups,
-// the lanes' offset groups.
-__global__ __launch_bounds__(64) void k_tok_emit(TokParams p)
+// bytes i .. i+7 of the 16 bytes (lo, hi); bytes past the 16th are zero
+__device__ __forceinline__ unsigned long long toks_get8(unsigned long long lo, unsigned long long hi, uint32_t i)
 {
-    extern __shared__ uint32_t tok_lds[];
+    if (i >= 8) return hi >> (8u * (i - 8u));
+    return i ? (lo >> (8u * i)) | (hi << (64u - 8u * i)) : lo;
+}
+
+__global__ __launch_bounds__(64) void k_tok_stream(TokParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[TOKS_OBUF];
+    __shared__ __attribute__((aligned(16))) uint32_t rbuf[TOKS_RBUF];
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x;
     if (p.ctrl->head.error != 0) return;
-    uint16_t *smask = reinterpret_cast<uint16_t *>(tok_lds);
-    uint8_t *rows_lds = reinterpret_cast<uint8_t *>(tok_lds + 128);
-    uint8_t *bytes_lds = rows_lds + 64 * TOK_ROW_PITCH;
-    uint32_t *offs_lds = reinterpret_cast<uint32_t *>(bytes_lds + 64 * TOK_ROW_PITCH);
     const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
-    const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
-    const uint32_t nb = p.piece_bytes / 64;
-    TokState st = tok_enter(p, a0);
-    const uint32_t *px = p.piece_x + (uint64_t) c * 3 * 64;
+    const uint32_t nsteps = p.chunk_bytes / TOKS_STEP;
     const uint64_t *cx = p.chunk_x + 3 * (uint64_t) c;
-    const uint64_t closed_before = cx[1] + px[64 + lane];
-    TokSink sink;
-    const uint32_t back = (uint32_t) (reinterpret_cast<uintptr_t>(p.out) & 15u);
-    sink.slot = bytes_lds + TOK_ROW_PITCH * lane;
-    sink.out = p.out - back;
-    sink.v = sink.v_first = cx[0] + px[lane] + 9 * closed_before + back;
-    sink.acc = 0;
-    UnpSink offs;
-    const uint32_t oback = (uint32_t) ((reinterpret_cast<uintptr_t>(p.rec_off) >> 2) & 3u);
-    offs.slot = offs_lds + UNP_SLOT_PITCH * lane;
-    offs.out = p.rec_off - oback;
-    offs.v = offs.v_first = cx[2] + px[128 + lane] + oback;
-    const uint8_t *mine = rows_lds + lane * TOK_ROW_PITCH;
-    const uint64_t tail0 = p.value << 8, tail1 = p.value >> 56; // NUL + value: 8 bytes, then 1
+    const unsigned long long tail0 = p.value << 8, tail1 = p.value >> 56; // NUL + value: 8 bytes, then 1
 
-    UnpRows cur, nxt, ahead;
-    tok_rows_load(p, c0, 0, lane, cur);
-    uint64_t W = tok_rows_mask(p, c0, 0, lane, cur, smask);
-    tok_rows_load(p, c0, 1, lane, nxt);
-    for (uint32_t b = 0; b < nb; b++) {
-        if (b + 2 <= nb) tok_rows_load(p, c0, b + 2, lane, ahead); // in flight during the walk
-        // this block's bytes to its lanes, the next block's masks
-        const uint64_t Wnext = tok_rows_mask(p, c0, b + 1, lane, nxt, smask, &cur, b, rows_lds);
-        const TokBlock blk = tok_block(p, W, Wnext, a0 + 64u * b, st);
-        // A word carried into the block may end right at its first byte; every other end
-        // of a word follows a run of kept bytes of this block.  So: that one first, then
-        // run by run (a word that crosses a block boundary is two runs), each with the
-        // end of its word if it is here -- the same steps in every lane.
-        if (blk.closes & 1ull) {
-            sink.append(tail0, 8); // NUL + value (src/serializer.h:63-83, :157-168)
-            sink.append(tail1, 1);
+    // positions count from 16-byte boundaries at or below the outputs
+    const uint32_t back = (uint32_t) (reinterpret_cast<uintptr_t>(p.out) & 15u);
+    uint8_t *const gout = p.out - back;
+    const uint32_t oback = (uint32_t) ((reinterpret_cast<uintptr_t>(p.rec_off) >> 2) & 3u);
+    uint32_t *const goff = p.rec_off - oback;
+    uint64_t A = cx[0], B = cx[1], S = cx[2]; // kept bytes / closed / started words before the step
+    const uint64_t v_first = A + 9 * B + back, r_first = S + oback;
+    uint64_t fl = v_first & ~(uint64_t) 15, rfl = r_first & ~(uint64_t) 3; // what lies below is stored (or not ours)
+
+    auto at_of = [&](uint32_t s) { return c0 + (uint64_t) s * TOKS_STEP + 16u * (uint32_t) lane; };
+    TokState st = tok_enter(p, c0);
+    // three steps' bytes in flight in a ring of four registers (the loop is unrolled by four so
+    // that no loaded value is moved: a move would wait for its load); a step's mask is made
+    // when it is next in line
+    uint4 R0 = tok_load16(p, at_of(0)), R1 = tok_load16(p, at_of(1)), R2 = tok_load16(p, at_of(2)), R3;
+    uint32_t m = tok_m16(p, at_of(0), R0);
+    auto step = [&](uint32_t s, const uint4 &cur, const uint4 &nxt, uint4 &fill) {
+        fill = tok_load16(p, at_of(s + 3)); // past the chunk: the next chunk's bytes, or nothing
+        const uint32_t m_n = tok_m16(p, at_of(s + 1), nxt);
+        const uint4 bytes = tok_in_place(p, at_of(s), cur);
+        const ToksLane x = toks_step(m, m_n, st, lane);
+        const uint32_t keep = x.keep, starts = x.starts, closes = x.closes;
+        // where the lane's output goes: one scan of three packed counts
+        const uint32_t kb = (uint32_t) __popc(keep), cl = (uint32_t) __popc(closes), sn = (uint32_t) __popc(starts);
+        const uint32_t packed = kb | (cl << 11) | (sn << 21);
+        const uint32_t incl = wave_incl_scan_u32(packed, lane);
+        const uint32_t excl = incl - packed;
+        const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+        const uint32_t tA = tot & 0x7FFu, tB = (tot >> 11) & 0x3FFu, tS = tot >> 21;
+        // positions inside the LDS images: obuf[0] is output byte fl, rbuf[0] is offset rfl
+        const uint32_t vbase = (uint32_t) (A + 9 * B + back - fl), rbase = (uint32_t) (S + oback - rfl); // < 16, < 4
+        const uint32_t opos = (uint32_t) (fl - back); // obuf[0] as a position in the records
+        uint32_t v = vbase + (excl & 0x7FFu) + 9u * ((excl >> 11) & 0x3FFu); // next output byte of this lane
+        uint32_t r = rbase + (excl >> 21);                                    // next record offset of this lane
+        // A word carried into the lane's bytes may end right at their first byte; every other
+        // end of a word follows a run of kept bytes of this lane.  So: that one first, then
+        // run by run, each with the end of its word if it is here.
+        const unsigned long long lo = (unsigned long long) bytes.x | ((unsigned long long) bytes.y << 32);
+        const unsigned long long hi = (unsigned long long) bytes.z | ((unsigned long long) bytes.w << 32);
+        if (closes & 1u) { // NUL + value (src/serializer.h:63-83, :157-168)
+            toks_put(obuf + v, tail0, 8);
+            obuf[v + 8] = (uint8_t) tail1;
+            v += 9;
         }
-        uint64_t runs = blk.keep & ~(blk.keep << 1);
+        uint32_t runs = keep & ~(keep << 1);
         while (runs) {
-            const uint32_t i = (uint32_t) __ffsll((unsigned long long) runs) - 1u;
+            const uint32_t i = (uint32_t) __builtin_ctz(runs);
             runs &= runs - 1;
-            if ((blk.starts >> i) & 1ull) offs.put((uint32_t) (sink.v - back));
-            const uint64_t rest = ~(blk.keep >> i);
-            const uint32_t len = rest ? (uint32_t) __ffsll((unsigned long long) rest) - 1u : 64u - i;
-            const uint64_t x = tok_row_get8(mine, i);
-            sink.append(len < 8 ? x & ((1ull << (8 * len)) - 1ull) : x, min(8u, len));
-            for (uint32_t j = 8; j < len; j += 8) { // rare: words of more than 8 bytes
-                const uint32_t k = min(8u, len - j);
-                const uint64_t y = tok_row_get8(mine, i + j);
-                sink.append(k < 8 ? y & ((1ull << (8 * k)) - 1ull) : y, k);
-            }
-            if (i + len < 64 && ((blk.closes >> (i + len)) & 1ull)) {
-                sink.append(tail0, 8);
-                sink.append(tail1, 1);
+            if ((starts >> i) & 1u) rbuf[r++] = opos + v;
+            const uint32_t rest = ~(keep >> i);
+            const uint32_t len = (uint32_t) __builtin_ctz(rest); // keep has 16 bits: the run ends inside them
+            toks_put(obuf + v, toks_get8(lo, hi, i), min(8u, len));
+            if (len > 8) toks_put(obuf + v + 8, toks_get8(lo, hi, i + 8), len - 8);
+            v += len;
+            if (i + len < 16 && ((closes >> (i + len)) & 1u)) {
+                toks_put(obuf + v, tail0, 8);
+                obuf[v + 8] = (uint8_t) tail1;
+                v += 9;
             }
         }
-        W = Wnext;
-        cur = nxt;
-        nxt = ahead;
+        __builtin_amdgcn_wave_barrier();
+        // The step's output: whole 16-byte units leave, the rest is carried to the next step.
+        // Always the same number of (predicated) store instructions, so that the waits for
+        // the text loads can leave the stores in flight.
+        A += tA;
+        B += tB;
+        S += tS;
+        const uint32_t top = (vbase + tA + 9u * tB) & ~15u, rtop = (rbase + tS) & ~3u;
+        const bool head = fl < v_first, rhead = rfl < r_first; // the chunk's first unit is shared with the chunk before
+        uint8_t *const gdst = gout + fl;
+        uint32_t *const rdst = goff + rfl;
+#pragma unroll
+        for (int j = 0; j < (TOKS_OBUF + 1023) / 1024; j++) {
+            const uint32_t o = 16u * ((uint32_t) lane + 64u * (uint32_t) j);
+            if (o < top && !(head && o == 0))
+                *reinterpret_cast<uint4 *>(gdst + o) = *reinterpret_cast<const uint4 *>(obuf + o);
+        }
+#pragma unroll
+        for (int j = 0; j < (TOKS_RBUF + 255) / 256; j++) {
+            const uint32_t o = 4u * ((uint32_t) lane + 64u * (uint32_t) j);
+            if (o < rtop && !(rhead && o == 0))
+                *reinterpret_cast<uint4 *>(rdst + o) = *reinterpret_cast<const uint4 *>(rbuf + o);
+        }
+        if (head && top > 0 && lane < 16 && fl + (uint32_t) lane >= v_first) gdst[lane] = obuf[lane];
+        if (rhead && rtop > 0 && lane < 4 && rfl + (uint32_t) lane >= r_first) rdst[lane] = rbuf[lane];
+        __builtin_amdgcn_wave_barrier();
+        if (top > 0) {
+            uint4 carry = make_uint4(0, 0, 0, 0);
+            if (lane == 0) carry = *reinterpret_cast<const uint4 *>(obuf + top);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) *reinterpret_cast<uint4 *>(obuf) = carry;
+            fl += top;
+        }
+        if (rtop > 0) {
+            uint4 carry = make_uint4(0, 0, 0, 0);
+            if (lane == 0) carry = *reinterpret_cast<const uint4 *>(rbuf + rtop);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) *reinterpret_cast<uint4 *>(rbuf) = carry;
+            rfl += rtop;
+        }
+        __builtin_amdgcn_wave_barrier();
+        m = m_n;
+    };
+    for (uint32_t s = 0; s < nsteps; s += 4) { // chunk_bytes is a multiple of 4 steps
+        step(s, R0, R1, R3);
+        step(s + 1, R1, R2, R0);
+        step(s + 2, R2, R3, R1);
+        step(s + 3, R3, R0, R2);
     }
-    sink.finish();
-    offs.finish();
+    // what is left below a 16-byte boundary belongs to this chunk up to its end
+    {
+        const uint64_t v_end = A + 9 * B + back, r_end = S + oback;
+        const uint64_t lo_v = fl > v_first ? fl : v_first;
+        for (uint64_t g = lo_v + (uint32_t) lane; g < v_end; g += 64) gout[g] = obuf[g - fl];
+        const uint64_t lo_r = rfl > r_first ? rfl : r_first;
+        for (uint64_t g = lo_r + (uint32_t) lane; g < r_end; g += 64) goff[g] = rbuf[g - rfl];
+    }
 }
 
 } // namespace mgs

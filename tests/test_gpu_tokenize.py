@@ -65,7 +65,8 @@ def _random_text(rng, n, alphabet):
     return a[rng.integers(0, len(a), size=n)]
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 4096, 16383, 16384, 16385, 100000])
+@pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097,
+                               8191, 8192, 8193, 16383, 16384, 16385, 100000])
 def test_tokenize_sizes(oracle, n):
     rng = np.random.default_rng(n)
     check(oracle, _random_text(rng, n, b"abcdefghijklmnopqrstuvwxyz     \n"))
@@ -73,7 +74,7 @@ def test_tokenize_sizes(oracle, n):
 
 
 def test_tokenize_corpus_many_chunks(oracle):
-    """A Zipf word corpus with lines, several chunks of 64 pieces."""
+    """A Zipf word corpus with lines, several hundred chunks."""
     rng = np.random.default_rng(3)
     vocab = [bytes(rng.integers(97, 123, size=rng.integers(1, 12), dtype=np.uint8)) for _ in range(5000)]
     ranks = np.minimum(rng.zipf(1.3, size=600000) - 1, len(vocab) - 1)
@@ -100,6 +101,21 @@ def test_tokenize_long_words(oracle, L):
     text = np.frombuffer(b"".join(parts) + b"z" * L, dtype=np.uint8)  # the last one ends with the text
     check(oracle, text)
     check(oracle, np.frombuffer(b"q" * L, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("start", [0, 1, 15, 16, 17, 1000, 1023, 1024, 1025, 2047, 3000, 4095, 4096, 4097, 5119, 8191])
+def test_tokenize_word_length_rule_at_step_and_chunk_edges(oracle, start):
+    """Words of 1022..1025 and 2048..2049 bytes that begin at every kind of offset inside a
+    1 KiB step of a wave and around the 4 KiB chunk edges: the length of a word is known from
+    this step's and the next step's masks, or from the text where a chunk begins inside it."""
+    torch, pk = _packer()
+    for L in (1, 1022, 1023, 1024, 1025, 2047, 2048, 2049, 3071, 3072, 4096, 9000):
+        head = (b"ab " * 4000)[:start]
+        if head and head[-1:] != b" ":
+            head = head[:-1] + b" "
+        for tail in (b"", b" ", b" cd ef\n", b"\0g"):
+            check(oracle, np.frombuffer(head + b"w" * L + tail, dtype=np.uint8), pk=pk)
+    pk.close()
 
 
 def test_tokenize_only_delimiters_and_only_words(oracle):
