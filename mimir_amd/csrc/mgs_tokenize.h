@@ -89,12 +89,20 @@ __device__ __forceinline__ uint4 tok_load16(const TokParams &p, uint64_t at)
 
 __device__ __forceinline__ uint32_t tok_m16(const TokParams &p, uint64_t at, const uint4 &v)
 {
-    auto zero = [](uint32_t w) { return ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu); }; // 0x80 per zero byte
-    auto delim = [&](uint32_t w) { // one bit per delimiter byte, lowest address first
-        const uint32_t t = zero(w) | zero(w ^ 0x20202020u) | zero(w ^ 0x0a0a0a0au);
-        return (((t >> 7) * 0x01020408u) >> 24) & 0xFu;
+    // 0x80 per delimiter byte (0x00, 0x0a, 0x20).  A delimiter has no bit outside 0x2a, and of
+    // the eight bytes that have none (bits 1, 3, 5 free) the three delimiters are those with
+    // bit 1 == bit 3 and not (bit 1 and bit 5): one zero-byte test instead of three.
+    auto delim = [](uint32_t w) {
+        const uint32_t c = w & 0xd5d5d5d5u;
+        const uint32_t cand = ~(((c & 0x7f7f7f7fu) + 0x7f7f7f7fu) | c | 0x7f7f7f7fu); // 0x80 per byte inside 0x2a
+        const uint32_t bad = ((w ^ (w >> 2)) | (w & (w >> 4))) & 0x02020202u;          // bit 1: not a delimiter after all
+        return cand & ~(bad << 6);
     };
-    const uint32_t m = ~(delim(v.x) | (delim(v.y) << 4) | (delim(v.z) << 8) | (delim(v.w) << 12)) & 0xFFFFu;
+    // one mask bit per byte, lowest address first: a dot product of the flag bytes with powers
+    // of two (flags are 0x80: the sums come out times 128)
+    const uint32_t lo = __builtin_amdgcn_udot4(delim(v.y), 0x80402010u, __builtin_amdgcn_udot4(delim(v.x), 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(delim(v.w), 0x80402010u, __builtin_amdgcn_udot4(delim(v.z), 0x08040201u, 0u, false), false);
+    const uint32_t m = ~((lo >> 7) | ((hi >> 7) << 8)) & 0xFFFFu;
     if (at >= p.nbytes) return 0;
     if (at + 16 > p.nbytes) return m >> (uint32_t) (at - (p.nbytes - 16));
     return m;
