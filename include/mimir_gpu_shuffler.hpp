@@ -61,6 +61,24 @@ class Exchange {
     virtual void alltoall_int(const int *send, int *recv) = 0;
     virtual void alltoallv_bytes(const char *sendbuf, const int *scount, const int *sdispl,
                                  char *recvbuf, const int *rcount, const int *rdispl) = 0;
+    // The same exchange counted in units of `unit_bytes` bytes (a power of two): counts and
+    // displacements are numbers of units, as with the contiguous type of 2^type_log_bytes
+    // bytes the reference commits when the send buffer exceeds 1 GiB
+    // (src/collectiveshuffler.h:46-53, :99-100, :630-645).  An MPI transport overrides this
+    // with that type; the default turns units into bytes, which fit an int for every buffer
+    // size the shufflers accept (up to 2 GiB).
+    virtual void alltoallv_units(const char *sendbuf, const int *scount, const int *sdispl, char *recvbuf,
+                                 const int *rcount, const int *rdispl, int unit_bytes)
+    {
+        if (unit_bytes == 1) {
+            alltoallv_bytes(sendbuf, scount, sdispl, recvbuf, rcount, rdispl);
+            return;
+        }
+        std::vector<int> b;
+        units_to_bytes(scount, sdispl, rcount, rdispl, unit_bytes, b);
+        const size_t n = (size_t) size();
+        alltoallv_bytes(sendbuf, &b[0], &b[n], recvbuf, &b[2 * n], &b[3 * n]);
+    }
     // The payload exchange on DEVICE memory (RCCL grouped send/recv, GPU-aware MPI, peer
     // copies over xGMI): same arguments as alltoallv_bytes, both buffers device pointers,
     // displacements 64-bit.  Blocking like MPI_Alltoallv: on return the receive image is
@@ -91,12 +109,39 @@ class Exchange {
         alltoallv_bytes(sendbuf, scount, sdispl, recvbuf, rcount, rdispl);
         return NULL;
     }
+    // Without an override a unit-counted non-blocking exchange completes at once through the
+    // blocking call (same order of collective calls on every rank).
+    virtual Request ialltoallv_units(const char *sendbuf, const int *scount, const int *sdispl, char *recvbuf,
+                                     const int *rcount, const int *rdispl, int unit_bytes)
+    {
+        if (unit_bytes == 1) return ialltoallv_bytes(sendbuf, scount, sdispl, recvbuf, rcount, rdispl);
+        alltoallv_units(sendbuf, scount, sdispl, recvbuf, rcount, rdispl, unit_bytes);
+        return NULL;
+    }
     virtual bool test(Request &req) { return req == NULL; } // true: complete, req released and NULL
     virtual void wait(Request &req)
     {
         while (!test(req)) {}
     }
     virtual void abort(int code) { std::exit(code); }
+
+    // counts and displacements in units -> the same in bytes: [scount | sdispl | rcount | rdispl]
+    void units_to_bytes(const int *scount, const int *sdispl, const int *rcount, const int *rdispl, int unit_bytes,
+                        std::vector<int> &out) const
+    {
+        const size_t n = (size_t) size();
+        out.resize(4 * n);
+        const int *src[4] = {scount, sdispl, rcount, rdispl};
+        for (int a = 0; a < 4; a++)
+            for (size_t i = 0; i < n; i++) {
+                const int64_t v = (int64_t) src[a][i] * unit_bytes;
+                if (v > 0x7fffffffLL) { // cannot happen below 2 GiB of send buffer
+                    fprintf(stderr, "Exchange: %lld bytes do not fit an int count\n", (long long) v);
+                    std::abort();
+                }
+                out[(size_t) a * n + i] = (int) v;
+            }
+    }
 };
 
 // ---- wire form of one typed object (bytestream<T>, src/serializer.h:40-223) ------
@@ -196,7 +241,13 @@ class GpuShuffler : public Writable<KeyType, ValType> {
         int unit = 0, tlb = 0;
         if (mgs_geometry(this->comm_buf_size, shuffle_size, &buf_size, &unit, &tlb) != MGS_OK)
             fail("The communication buffer is too small!\n"); // src/collectiveshuffler.h:38-41
-        if (tlb != 0) fail("GpuShuffler: MIMIR_COMM_SIZE above 1 GiB is not supported\n");
+        // Above 1 GiB the reference counts its all-to-all-v in units of 2^type_log_bytes bytes
+        // (src/collectiveshuffler.h:46-53).  Units of two bytes (up to 2 GiB) are taken here; with
+        // larger ones the reference's own exchange no longer works -- `i * (int) buf_size`
+        // overflows (:635) and save_data steps over `recv_count & (unit - 1)` bytes of padding
+        // (:582), which is the padding only for units of two -- so there is nothing to match.
+        if (tlb > 1) fail("GpuShuffler: MIMIR_COMM_SIZE above 2 GiB is not supported\n");
+        type_log_bytes = tlb;
         handle = NULL;
         stager = NULL;
         memset(&win, 0, sizeof(win));
@@ -239,6 +290,8 @@ class GpuShuffler : public Writable<KeyType, ValType> {
         d_r_displs.assign((size_t) shuffle_size, 0);
         send_bytes = recv_bytes = 0;
         device_exchanges = 0;
+        a2a_s_count.assign((size_t) shuffle_size, 0);
+        a2a_r_count.assign((size_t) shuffle_size, 0);
         a2a_s_displs.assign((size_t) shuffle_size, 0);
         a2a_r_displs.assign((size_t) shuffle_size, 0);
         done_flag = done_count = 0;
@@ -362,10 +415,16 @@ class GpuShuffler : public Writable<KeyType, ValType> {
             if (send_count[(size_t) i] == -1) send_count[(size_t) i] = 0;
         }
         if (done_count >= shuffle_size) return;
-        int64_t recvcount = 0;
+        // counts and displacements of the host exchange in units (:630-639); the device exchange
+        // takes bytes and leaves no padding
+        const int tb = type_log_bytes, unit = 1 << tb;
+        int64_t recvcount = 0, recvunits = 0;
         for (int i = 0; i < shuffle_size; i++) {
-            a2a_s_displs[(size_t) i] = (int) (i * buf_size);
-            a2a_r_displs[(size_t) i] = (int) recvcount;
+            a2a_s_count[(size_t) i] = (send_count[(size_t) i] + unit - 1) >> tb;
+            a2a_r_count[(size_t) i] = (recv_count[(size_t) i] + unit - 1) >> tb;
+            a2a_s_displs[(size_t) i] = (int) (((int64_t) i * buf_size) >> tb);
+            a2a_r_displs[(size_t) i] = (int) recvunits;
+            recvunits += a2a_r_count[(size_t) i];
             d_s_displs[(size_t) i] = (int64_t) i * buf_size;
             d_r_displs[(size_t) i] = recvcount;
             recvcount += recv_count[(size_t) i];
@@ -404,12 +463,12 @@ class GpuShuffler : public Writable<KeyType, ValType> {
             const void *image = NULL;
             if (mgs_stager_send_image_host(stager, &image, &send_offset) != MGS_OK)
                 fail(mgs_stager_last_error(stager));
-            comm->alltoallv_bytes(static_cast<const char *>(image), send_count.data(), a2a_s_displs.data(),
-                                  recv_buffer.data(), recv_count.data(), a2a_r_displs.data());
-            for (int i = 0; i < shuffle_size; i++) { // save_data, :563-585
+            comm->alltoallv_units(static_cast<const char *>(image), a2a_s_count.data(), a2a_s_displs.data(),
+                                  recv_buffer.data(), a2a_r_count.data(), a2a_r_displs.data(), unit);
+            for (int i = 0; i < shuffle_size; i++) { // save_data, :563-585: a source's records, then its padding
                 if (recv_count[(size_t) i] > 0) {
                     begin_source(i);
-                    deliver(recv_buffer.data() + a2a_r_displs[(size_t) i], recv_count[(size_t) i]);
+                    deliver(recv_buffer.data() + ((int64_t) a2a_r_displs[(size_t) i] << tb), recv_count[(size_t) i]);
                 }
             }
         }
@@ -518,7 +577,8 @@ class GpuShuffler : public Writable<KeyType, ValType> {
     mgs_stager *stager;
     mgs_stage_window win; // the staging buffer, for the inlined put in write()
     std::vector<char> recv_buffer, key_scratch, val_scratch;
-    std::vector<int> send_count, recv_count, a2a_s_displs, a2a_r_displs;
+    int type_log_bytes; // the exchange counts in units of 1 << type_log_bytes bytes
+    std::vector<int> send_count, recv_count, a2a_s_count, a2a_r_count, a2a_s_displs, a2a_r_displs;
     std::vector<int64_t> d_s_displs, d_r_displs;
     uint64_t send_bytes, recv_bytes;
     int device_exchanges;
@@ -585,7 +645,7 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
     struct MsgBuf {
         char *send_buffer; // page-locked: the partitions are copied here straight from the GPU
         std::vector<char> recv_buffer;
-        std::vector<int> send_offset, recv_count, s_displs, r_displs;
+        std::vector<int> send_offset, recv_count, s_count, r_count, s_displs, r_displs;
         uint64_t token;
         State state;
         bool counts_known;
@@ -601,6 +661,8 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
         m->recv_buffer.resize((size_t) this->buf_size * P);
         m->send_offset.assign(P, 0);
         m->recv_count.assign(P, 0);
+        m->s_count.assign(P, 0);
+        m->r_count.assign(P, 0);
         m->s_displs.assign(P, 0);
         m->r_displs.assign(P, 0);
         m->token = 0;
@@ -702,19 +764,23 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
                     continue;
                 }
                 if (m->counts_known && m->token == a2av_token && this->done_count < P) {
-                    int64_t recvcount = 0;
+                    const int tb = this->type_log_bytes, unit = 1 << tb; // :322-335
+                    int64_t recvcount = 0, recvunits = 0;
                     for (int i = 0; i < P; i++) {
                         if (m->send_offset[(size_t) i] == -1) m->send_offset[(size_t) i] = 0;
                         if (m->recv_count[(size_t) i] == -1) m->recv_count[(size_t) i] = 0;
-                        m->s_displs[(size_t) i] = (int) (i * this->buf_size);
-                        m->r_displs[(size_t) i] = (int) recvcount;
+                        m->s_count[(size_t) i] = (m->send_offset[(size_t) i] + unit - 1) >> tb;
+                        m->r_count[(size_t) i] = (m->recv_count[(size_t) i] + unit - 1) >> tb;
+                        m->s_displs[(size_t) i] = (int) (((int64_t) i * this->buf_size) >> tb);
+                        m->r_displs[(size_t) i] = (int) recvunits;
+                        recvunits += m->r_count[(size_t) i];
                         recvcount += m->recv_count[(size_t) i];
                         this->send_bytes += (uint64_t) m->send_offset[(size_t) i];
                     }
                     this->recv_bytes += (uint64_t) recvcount;
-                    m->a2av_req = this->comm->ialltoallv_bytes(m->send_buffer, m->send_offset.data(),
+                    m->a2av_req = this->comm->ialltoallv_units(m->send_buffer, m->s_count.data(),
                                                                m->s_displs.data(), m->recv_buffer.data(),
-                                                               m->recv_count.data(), m->r_displs.data());
+                                                               m->r_count.data(), m->r_displs.data(), unit);
                     m->state = ShuffleMsgPending;
                     a2av_token += 1;
                 }
@@ -744,7 +810,8 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
         for (int i = 0; i < this->shuffle_size; i++) {
             if (m->recv_count[(size_t) i] > 0) {
                 this->begin_source(i);
-                this->deliver(m->recv_buffer.data() + m->r_displs[(size_t) i], m->recv_count[(size_t) i]);
+                this->deliver(m->recv_buffer.data() + ((int64_t) m->r_displs[(size_t) i] << this->type_log_bytes),
+                              m->recv_count[(size_t) i]);
             }
         }
     }

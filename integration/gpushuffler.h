@@ -19,6 +19,10 @@ class MpiExchange : public mimir_gpu::Exchange {
     void alltoallv_bytes(const char *sb, const int *sc, const int *sd,
                          char *rb, const int *rc, const int *rd)   // :643-645
     { MPI_Alltoallv((void *) sb, (int *) sc, (int *) sd, MPI_BYTE, rb, (int *) rc, (int *) rd, MPI_BYTE, comm); }
+    // send buffers above 1 GiB: counts in units of the contiguous type the reference commits, :99-100, :630-645
+    void alltoallv_units(const char *sb, const int *sc, const int *sd, char *rb, const int *rc, const int *rd, int unit)
+    { MPI_Datatype t; MPI_Type_contiguous(unit, MPI_BYTE, &t); MPI_Type_commit(&t);
+      MPI_Alltoallv((void *) sb, (int *) sc, (int *) sd, t, rb, (int *) rc, (int *) rd, t, comm); MPI_Type_free(&t); }
     void abort(int code) { MPI_Abort(MPI_COMM_WORLD, code); }      // LOG_ERROR, src/log.h:70-78
     // for NBGpuShuffler: counts and payloads on two duplicated communicators,
     // src/nbcollectiveshuffler.h:68-69, :237-239, :347-351, :291/:364 (MPI_Test)
@@ -29,6 +33,12 @@ class MpiExchange : public mimir_gpu::Exchange {
     { dup(); MPI_Request *q = new MPI_Request;
       MPI_Ialltoallv((void *) sb, (int *) sc, (int *) sd, MPI_BYTE, rb, (int *) rc, (int *) rd, MPI_BYTE, a2av_comm, q);
       return q; }
+    Request ialltoallv_units(const char *sb, const int *sc, const int *sd, char *rb, const int *rc, const int *rd,
+                             int unit)                             // src/nbcollectiveshuffler.h:109-110, :322-351
+    { dup(); MPI_Datatype t; MPI_Type_contiguous(unit, MPI_BYTE, &t); MPI_Type_commit(&t);
+      MPI_Request *q = new MPI_Request;
+      MPI_Ialltoallv((void *) sb, (int *) sc, (int *) sd, t, rb, (int *) rc, (int *) rd, t, a2av_comm, q);
+      MPI_Type_free(&t); return q; }                               // freed once the exchange in flight has ended
     bool test(Request &req)
     { if (!req) return true; int flag = 0; MPI_Test((MPI_Request *) req, &flag, MPI_STATUS_IGNORE);
       if (flag) { delete (MPI_Request *) req; req = NULL; } return flag != 0; }

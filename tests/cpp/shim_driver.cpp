@@ -62,6 +62,7 @@ struct NbReq {
     int *recv_counts;
     char *recvbuf;
     const int *rcount, *rdispl;
+    std::vector<int> own; // byte counts of a unit-counted exchange (they must live as long as the request)
 };
 
 class ThreadExchange : public Exchange {
@@ -147,6 +148,21 @@ class ThreadExchange : public Exchange {
         }
         op.arrived++;
         return new NbReq{true, a2av_seq++, NULL, recvbuf, rcount, rdispl};
+    }
+    // units of more than one byte (send buffers above 1 GiB): the same exchange on byte counts
+    Request ialltoallv_units(const char *sendbuf, const int *scount, const int *sdispl, char *recvbuf,
+                             const int *rcount, const int *rdispl, int unit_bytes)
+    {
+        if (unit_bytes == 1) return ialltoallv_bytes(sendbuf, scount, sdispl, recvbuf, rcount, rdispl);
+        std::vector<int> b;
+        units_to_bytes(scount, sdispl, rcount, rdispl, unit_bytes, b);
+        const size_t n = (size_t) s->P;
+        NbReq *q = static_cast<NbReq *>(ialltoallv_bytes(sendbuf, &b[0], &b[n], recvbuf, &b[2 * n], &b[3 * n]));
+        std::lock_guard<std::mutex> g(s->mu);
+        q->own.swap(b);
+        q->rcount = &q->own[2 * n];
+        q->rdispl = &q->own[3 * n];
+        return q;
     }
     bool test(Request &req)
     {

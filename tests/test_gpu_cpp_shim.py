@@ -139,3 +139,43 @@ def test_cpp_combiner_shim_matches_reference(oracle, P, comm):
             assert got == sinks[r], f"rank {r}: sink differs"
             kv, times, _ = open(os.path.join(outd, f"rank{r}.txt")).read().split()
             assert int(kv) == stats[r]["kvcount"] and int(times) == stats[r]["shuffle_times"]
+
+
+@pytest.mark.parametrize("nb", [False, True])
+def test_cpp_shim_send_buffer_above_one_gib(oracle, nb):
+    """MIMIR_COMM_SIZE just above 1 GiB: the exchange counts in units of two bytes
+    (type_log_bytes = 1, src/collectiveshuffler.h:46-53, :630-639): partitions of odd length
+    travel with a byte of padding, and a source's records are found behind the padded run of
+    the source before it (:582).  One round (nothing fills half a gibibyte here)."""
+    assert os.path.exists(DRIVER), "tests/cpp/shim_driver not built (__graft_entry__.build)"
+    P, kind = 2, "words"
+    comm, stage = (1 << 30) + (1 << 21), 1 << 16
+    assert capi.geometry(comm, P)[2] == 1
+    counts = [4001, 2503]
+    streams, lay = [], None
+    with tempfile.TemporaryDirectory() as d:
+        ind, outd = os.path.join(d, "in"), os.path.join(d, "out")
+        os.makedirs(ind)
+        os.makedirs(outd)
+        for r in range(P):
+            blob, offs, lay = make_stream(kind, r, counts[r])
+            streams.append((blob, offs, counts[r]))
+            blob.tofile(os.path.join(ind, f"rank{r}.blob"))
+            np.asarray(offs, dtype=np.uint64).tofile(os.path.join(ind, f"rank{r}.off"))
+        subprocess.run([DRIVER, kind, str(P), str(comm), str(stage), ind, outd, "1"] + (["nb"] if nb else []),
+                       check=True, timeout=300, env=dict(os.environ, MGS_SHIM_DEVICE_EXCHANGE="0"))
+        buf_size = capi.geometry(comm, P)[0]
+        per, rounds, kvcount = refsim.simulate_streams(oracle, lay, streams, P, buf_size)
+        odd = 0
+        for r in range(P):
+            data = np.fromfile(os.path.join(outd, f"rank{r}.out"), dtype=np.uint8).tobytes()
+            off = np.fromfile(os.path.join(outd, f"rank{r}.outoff"), dtype=np.uint64)
+            src = np.fromfile(os.path.join(outd, f"rank{r}.outsrc"), dtype=np.int32)
+            by_src = [[] for _ in range(P)]
+            for i in range(len(src)):
+                by_src[int(src[i])].append(data[int(off[i]):int(off[i + 1])])
+            for s_ in range(P):
+                assert by_src[s_] == per[r][s_], f"rank {r}: records from {s_} differ"
+                odd += sum(len(x) for x in per[r][s_]) & 1 if s_ != r else 0
+            assert int(open(os.path.join(outd, f"rank{r}.txt")).read().split()[0]) == kvcount[r]
+        assert odd > 0, "no partition of odd length: the padding was not exercised"
