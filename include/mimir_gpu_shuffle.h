@@ -531,7 +531,8 @@ int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records,
  * packs (the non-blocking shuffler tests its exchanges in flight,
  * src/nbcollectiveshuffler.h:279-387): _begin enqueues the upload and the pack
  * kernels (mgs_pack_device_async), _end waits and reports as mgs_stager_pack does.
- * No other stager call between the two. */
+ * No other stager call between the two: put, the send image views and
+ * mgs_stager_round_done return MGS_ERR_STATE until _end has run. */
 int mgs_stager_pack_begin(mgs_stager *s);
 int mgs_stager_pack_end(mgs_stager *s, mgs_round *out,
                         const void **local_records, int *drained);

@@ -294,6 +294,10 @@ int mgs_stager_put(mgs_stager *s, const void *key, uint32_t klen, const void *va
                       (long long) len, (long long) s->cap);
         return MGS_ERR_RECORD_SIZE;
     }
+    if (s->in_flight) {
+        s->err = "a pack is in flight on this stager: call mgs_stager_pack_end first";
+        return MGS_ERR_STATE;
+    }
     if (s->uploaded || s->nrec >= s->max_rec || s->used + len > s->cap) {
         s->want_refill = true;
         return 1;
@@ -461,6 +465,10 @@ int mgs_stager_pack(mgs_stager *s, mgs_round *out, const void **local_records, i
 int mgs_stager_send_image_host(mgs_stager *s, const void **host_image, const int64_t **send_offset)
 {
     if (!s || !host_image || !send_offset) return MGS_ERR_ARG;
+    if (s->in_flight) {
+        s->err = "a pack is in flight on this stager: call mgs_stager_pack_end first";
+        return MGS_ERR_STATE;
+    }
     int prev = -1;
     (void) hipGetDevice(&prev);
     (void) hipSetDevice(s->desc.device);
@@ -489,6 +497,10 @@ int mgs_stager_send_image_host(mgs_stager *s, const void **host_image, const int
 int mgs_stager_send_image_to(mgs_stager *s, void *host_dst, const int64_t **send_offset)
 {
     if (!s || !host_dst || !send_offset) return MGS_ERR_ARG;
+    if (s->in_flight) {
+        s->err = "a pack is in flight on this stager: call mgs_stager_pack_end first";
+        return MGS_ERR_STATE;
+    }
     int prev = -1;
     (void) hipGetDevice(&prev);
     (void) hipSetDevice(s->desc.device);
@@ -526,6 +538,10 @@ void mgs_host_free(void *p)
 int mgs_stager_send_image_device(mgs_stager *s, void **d_image, const int64_t **send_offset)
 {
     if (!s || !d_image || !send_offset) return MGS_ERR_ARG;
+    if (s->in_flight) {
+        s->err = "a pack is in flight on this stager: call mgs_stager_pack_end first";
+        return MGS_ERR_STATE;
+    }
     *d_image = s->d_image;
     *send_offset = s->send_offset;
     return MGS_OK;
@@ -613,6 +629,10 @@ int mgs_stager_recv_to_host(mgs_stager *s, int64_t nbytes, const void **host_rec
 int mgs_stager_round_done(mgs_stager *s)
 {
     if (!s) return MGS_ERR_ARG;
+    if (s->in_flight) {
+        s->err = "a pack is in flight on this stager: call mgs_stager_pack_end first";
+        return MGS_ERR_STATE;
+    }
     memset(s->send_offset, 0, sizeof(s->send_offset));
     if (s->combine_op >= 0) {
         // the exchange forgets the round's keys (garbage_collection, src/combinecollectiveshuffler.h:237):

@@ -56,6 +56,11 @@ def test_pack_in_two_calls_and_image_into_caller_buffer(oracle, rank):
     assert lib.mgs_stager_pack_end(s1, C.byref(r1), C.byref(loc1), C.byref(dr1)) == capi.ERR_STATE
     assert lib.mgs_stager_pack_begin(s1) == capi.OK
     assert lib.mgs_stager_pack_begin(s1) == capi.ERR_STATE
+    # nothing else between the two halves: the image is being written
+    img0, so0 = C.c_void_p(), C.POINTER(C.c_int64)()
+    assert lib.mgs_stager_send_image_host(s1, C.byref(img0), C.byref(so0)) == capi.ERR_STATE
+    assert lib.mgs_stager_round_done(s1) == capi.ERR_STATE
+    assert lib.mgs_stager_put(s1, b"12345678", 8, b"12345678", 8) == capi.ERR_STATE
     assert lib.mgs_stager_pack_end(s1, C.byref(r1), C.byref(loc1), C.byref(dr1)) == capi.OK
     assert lib.mgs_stager_pack(s2, C.byref(r2), C.byref(loc2), C.byref(dr2)) == capi.OK
     assert dr1.value == 1 and dr2.value == 1
