@@ -324,3 +324,79 @@ def test_streams_empty_call_and_wrong_result_call(oracle):
     got = pk.streams_result()
     assert got.next == n and got.n_rounds > 1
     pk.close()
+
+
+def test_full_size_streams_at_the_reference_geometry(oracle):
+    """The benchmarked call at the benchmarked size: 1e9 seed-42 <u64,u64> records, P = 8,
+    MIMIR_COMM_SIZE = 64M (8 MiB partitions), streams layout.  Checked on the device:
+    the streams hold what the one-round image holds, the rounds lie back to back, every
+    round ends exactly where the next record of some destination no longer fits
+    (src/collectiveshuffler.h:143-162), and four rounds -- first, second, middle, last --
+    are byte-equal to the oracle driven from the previous round's end on a host copy of
+    just their records."""
+    import torch
+    from mimir_amd.packer import DevicePacker, synth_u64_records
+    n, P = 1_000_000_000, 8
+    buf, _, tlb = capi.geometry(64 << 20, P)
+    assert buf == 8 << 20 and tlb == 0
+    dev = torch.device("cuda:0")
+    rec = synth_u64_records(n, seed=42)
+    glay = capi.Layout.make(capi.KEY_FIXED, 8, capi.VAL_FIXED, 8)
+    olay = O.Layout.make(O.KEY_FIXED, 8, O.VAL_FIXED, 8)
+    total = 16 * n
+    max_rounds = int(total / P / buf * 1.15) + 8
+    stream_cap = (total // P + total // 64 + 65536) // 16 * 16
+    pk = DevicePacker(glay, P, -1, buf, max_records=n)
+    streams = torch.empty(P * stream_cap, dtype=torch.uint8, device=dev)
+    got = pk.pack_streams(rec, n, streams, stream_cap, max_rounds)
+    assert pk.last_algo() == "onesweep16"
+    # (iv) the round count of this batch, and nothing lost
+    assert got.next == n and got.n_rounds == 239
+    so, base, nxt = got.round_send_offset, got.round_base, got.round_next.astype(np.int64)
+    assert int(so.sum()) == total
+    # (ii) rounds lie back to back in every stream, the first at byte 0
+    assert not base[0].any()
+    assert np.array_equal(base[1:], base[:-1] + so[:-1])
+    # (iii) no partition above its capacity; the record that opened round k + 1 did not fit round k
+    assert int(so.max()) <= buf and int(so.min()) >= 0
+    assert np.all(np.diff(nxt) > 0) and nxt[-1] == n
+    fill = base[-1] + so[-1]
+
+    # (i) against the one-round image of the same records (oracle-sampled in test_full_size_properties)
+    big = 16 * (n // P + n // 64 + 4096)
+    pk1 = DevicePacker(glay, P, -1, big, max_records=n)
+    image = pk1.new_send_image()
+    dest = torch.empty(n, dtype=torch.uint8, device=dev)
+    one = pk1.pack(rec, n, image, dest_out=dest)
+    assert one.next == n and one.send_offset.tolist() == fill.tolist()
+    for p in range(P):
+        f = int(fill[p])
+        assert torch.equal(streams[p * stream_cap:p * stream_cap + f], image[p * big:p * big + f]), f"stream {p}"
+    del image
+    openers = torch.from_numpy(nxt[:-1]).to(dev)
+    d_open = dest[openers].cpu().numpy().astype(np.int64)
+    k = np.arange(got.n_rounds - 1)
+    assert np.all(so[k, d_open] + 16 > buf), "a round ended although the next record fitted"
+    # sampled destinations against the oracle
+    rng = np.random.default_rng(2)
+    pick = np.unique(np.concatenate([rng.integers(0, n, size=100000), nxt[:-1], nxt[:-1] - 1, [0, n - 1]]))
+    words = rec.view(torch.int64).view(n, 2)
+    sample = words[torch.from_numpy(pick).to(dev)].cpu().numpy().view(np.uint8).reshape(-1)
+    _, want_dest = oracle.dest(olay, sample, None, len(pick), P)
+    assert np.array_equal(dest[torch.from_numpy(pick).to(dev)].cpu().numpy(), want_dest.astype(np.uint8))
+    del dest
+
+    # (v) four rounds against the oracle, each driven from the end of the round before
+    for kk in (0, 1, got.n_rounds // 2, got.n_rounds - 1):
+        s = int(nxt[kk - 1]) if kk else 0
+        e = min(n, int(nxt[kk]) + 4096)            # a few records beyond the cut, so that the oracle finds it
+        host = rec[16 * s:16 * e].cpu().numpy()
+        w = oracle.pack_round(olay, host, None, e - s, 0, P, -1, buf)
+        assert s + w["next"] == int(nxt[kk]), f"round {kk}"
+        assert w["send_offset"].tolist() == so[kk].tolist(), f"round {kk}"
+        for p in range(P):
+            o = p * stream_cap + int(base[kk][p])
+            view = streams[o:o + int(so[kk][p])].cpu().numpy()
+            assert np.array_equal(view, w["partitions"][p]), f"round {kk} partition {p}"
+    pk.close()
+    pk1.close()
