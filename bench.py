@@ -371,8 +371,9 @@ def main():
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     kname = pk.tuning_name() if pk.last_algo() == "onesweep16" else pk.last_algo()
     # variant names start with the kernel family's letter (t = the plain kernel)
-    kernel = {"onesweep16": "k_onesweep16" + ("<" if kname.startswith("t") else kname[:1]),
-              "onesweepv": "k_onesweepv", "onesweepd": "k_onesweepd", "generic": "k_gen_scatter"}[pk.last_algo()]
+    kernel = pk.last_kernel()
+    if kernel == "k_onesweep16":
+        kernel += "<" if kname.startswith("t") else kname[:1]
     if not in_kernel:
         kernel += f" x {stats['rounds']} rounds (one kernel sequence per round; wall time of the pack calls)"
     out = {

@@ -102,6 +102,12 @@ typedef struct mgs_desc {
  * LDS-image kernel packs one round per call. */
 #define MGS_FLAG_OSV_ROUNDS_KERNEL 1
 #define MGS_FLAG_OSV_IMAGE_KERNEL 2
+/* The LDS-image kernel comes in two forms.  Records of ONE string key with a
+ * fixed-width or absent value, and fixed widths up to 32 bytes, take the form
+ * that loads every record straight into registers (k_onesweepr); every other
+ * layout takes the form that stages a tile's bytes in LDS first (k_onesweepv).
+ * This flag keeps the staged form for every call (measurement, tests). */
+#define MGS_FLAG_OSV_STAGED_KERNEL 4
 
 typedef struct mgs_handle mgs_handle;
 
@@ -349,8 +355,13 @@ int mgs_pack_device_noalloc(mgs_handle *h, const void *d_records,
                             void *stream, mgs_round *out);
 
 /* Name of the kernel path the last pack call on this handle ran
- * ("generic" / "onesweep16"). */
+ * ("generic" / "onesweep16" / "onesweepv" / "onesweepd"). */
 const char *mgs_last_algo(const mgs_handle *h);
+
+/* Name of the dominant kernel of that path ("k_gen_scatter", "k_onesweep16",
+ * "k_onesweepv", "k_onesweepr", "k_onesweepd"): what mgs_last_kernel_ms times
+ * and what a profiler's kernel trace shows. */
+const char *mgs_last_kernel(const mgs_handle *h);
 
 /* The descriptor the handle was created with. */
 int mgs_get_desc(const mgs_handle *h, mgs_desc *out);

@@ -15,7 +15,7 @@ KEY_FIXED, KEY_CSTR = 0, 1
 VAL_VOID, VAL_FIXED, VAL_CSTR = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_ONESWEEP16, ALGO_ONESWEEPV = 0, 1, 2, 3
 COMBINE_SUM_U64, COMBINE_MIN_U64, COMBINE_MAX_U64 = 0, 1, 2
-FLAG_OSV_ROUNDS_KERNEL, FLAG_OSV_IMAGE_KERNEL = 1, 2
+FLAG_OSV_ROUNDS_KERNEL, FLAG_OSV_IMAGE_KERNEL, FLAG_OSV_STAGED_KERNEL = 1, 2, 4
 
 OK = 0
 ERR_ARG, ERR_HIP, ERR_RECORD_SIZE, ERR_LOCAL_OVERFLOW = -1, -2, -3, -4
@@ -80,6 +80,7 @@ SYMBOLS = {
     "mgs_destroy": (None, [_VP]),
     "mgs_last_error": (C.c_char_p, [_VP]),
     "mgs_last_algo": (C.c_char_p, [_VP]),
+    "mgs_last_kernel": (C.c_char_p, [_VP]),
     "mgs_pack_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64, _VP,
                                   _VP, _VP, C.c_int64, _VP, C.c_int, _VP,
                                   C.POINTER(Round)]),

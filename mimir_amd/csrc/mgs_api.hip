@@ -16,6 +16,7 @@
 #include "mgs_onesweep16w.h"
 #include "mgs_onesweepv.h"
 #include "mgs_onesweepd.h"
+#include "mgs_onesweepr_api.h"
 #include "mgs_unpack.h"
 #include "mgs_tokenize.h"
 #include "mgs_group.h"
@@ -171,6 +172,9 @@ struct mgs_handle {
     int ov_k = 4;             // (unused) records per worker lane of the last variable-width call
     double ov_bytes_per_record = 16.0; // variable width: average record length seen last
     int ov_shrink = 0;        // ... and how much smaller than that length suggests the tile must be
+    int osr_nq = 0;           // k_onesweepr, variable width: register quads per record (0: not chosen yet)
+    bool pending_osr = false; // the call in flight runs k_onesweepr
+    const char *last_kernel = "none";
     int pending_ov_k = 4;
     // call in flight
     bool pending = false;
@@ -288,6 +292,8 @@ const char *mgs_last_error(const mgs_handle *h)
 }
 
 const char *mgs_last_algo(const mgs_handle *h) { return h ? h->last_algo : "none"; }
+
+const char *mgs_last_kernel(const mgs_handle *h) { return h ? h->last_kernel : "none"; }
 
 void mgs_destroy(mgs_handle *h)
 {
@@ -477,6 +483,34 @@ static int ov_pick_k(bool image_kernel, double bytes_per_record)
     return image_kernel ? ov_pick_k_legacy(bytes_per_record) : od_pick_k(bytes_per_record);
 }
 
+// k_onesweepr (records straight into registers) serves the LDS-image kernel's layout modes 1
+// and 2 for records that fit its registers.  MGS_OSR=0 in the environment, or
+// MGS_FLAG_OSV_STAGED_KERNEL in mgs_desc.flags, keep the staged kernel (k_onesweepv) for A/B runs.
+static bool osr_enabled(const mgs_handle *h)
+{
+    static const char *env = getenv("MGS_OSR");
+    if (env && atoi(env) == 0) return false;
+    return (h->desc.flags & MGS_FLAG_OSV_STAGED_KERNEL) == 0;
+}
+// Records per lane and register quads for records of about `bytes_per_record` bytes (variable
+// width: 1.25 times the average seen), given the quads the handle has settled on (0: none yet).
+static bool osr_pick(int lm, bool a4, double bytes_per_record, int nq_hint, int shrink, int *k_out, int *nq_out)
+{
+    static const int cand[4][2] = {{4, 1}, {4, 2}, {2, 2}, {1, 2}};
+    int skipped = 0;
+    for (const auto &c : cand) {
+        const int k = c[0], nq = c[1];
+        if (nq < nq_hint || !osr_has(k, nq, lm, a4)) continue;
+        if ((double) (kOvLanes * k) * bytes_per_record > (double) osr_image_bytes(nq)) continue;
+        if (nq == 1 && bytes_per_record > 16.0 * 1.25) continue;
+        if (skipped++ < shrink) continue; // a tile of this size did not fit last time
+        *k_out = k;
+        *nq_out = nq;
+        return true;
+    }
+    return false;
+}
+
 // Enqueue one pack call.  noalloc: the control block and the chained-scan arrays live
 // in the device's static scratch array, nothing is allocated, only the one-sweep
 // kernels are available.
@@ -606,6 +640,24 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
     if (h->fixed_len == 0 && h->ov_shrink > 0) // the LDS-image kernel exists for K = 4, 2, 1 only
         ov_k = image_kernel ? std::max(1, ov_k >> std::min(h->ov_shrink, 2)) : std::max(1, ov_k - h->ov_shrink);
     if (image_kernel && ov_k == 3) ov_k = 2;
+    // the register kernel instead of the staged one: layout modes 1 and 2, records that fit its registers
+    const mgs_layout &LY = D.layout;
+    const int ov_lm = (LY.val_kind == MGS_VAL_CSTR) ? 0 : (LY.key_kind == MGS_KEY_CSTR ? (LY.key_count == 1 ? 1 : 0) : 2);
+    bool use_osr = false, osr_a4 = false;
+    int osr_k = 0, osr_nq = 0;
+    if (image_kernel && ov_ok && ov_lm != 0 && osr_enabled(h) && P + (D.rank >= 0 ? 1 : 0) <= OS_MAXP) {
+        if (h->fixed_len) {
+            osr_a4 = (h->fixed_len % 4) == 0 && ((uintptr_t) d_send_image % 4) == 0 && (part_cap % 4) == 0
+                     && (D.rank < 0 || ((uintptr_t) d_local_out % 4) == 0);
+            for (int b = 0; b < P && osr_a4; b++) osr_a4 = (h->pending_init[b] % 4) == 0;
+            use_osr = h->fixed_len <= 32 && osr_pick(ov_lm, osr_a4, (double) h->fixed_len, 0, 0, &osr_k, &osr_nq);
+        }
+        else {
+            if (h->osr_nq == 0) h->osr_nq = h->ov_bytes_per_record <= 14.5 ? 1 : 2;
+            use_osr = osr_pick(ov_lm, false, 1.25 * h->ov_bytes_per_record, h->osr_nq, h->ov_shrink, &osr_k, &osr_nq);
+        }
+        if (use_osr) ov_k = osr_k;
+    }
     if (algo == MGS_ALGO_AUTO)
         algo = os_ok ? MGS_ALGO_ONESWEEP16 : (ov_ok ? MGS_ALGO_ONESWEEPV : MGS_ALGO_GENERIC);
     if (sa && algo == MGS_ALGO_GENERIC) {
@@ -773,7 +825,9 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             hipLaunchKernelGGL(k_os_finalize, dim3(1), dim3(64), 0, stream, p);
         }
         h->last_algo = "onesweep16";
+        h->last_kernel = "k_onesweep16";
         h->pending_osv = false;
+        h->pending_osr = false;
     }
     else {
         const bool osv = algo == MGS_ALGO_ONESWEEPV;
@@ -847,15 +901,25 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             const int lm = (L.val_kind == MGS_VAL_CSTR) ? 0 : (L.key_kind == MGS_KEY_CSTR ? (L.key_count == 1 ? 1 : 0) : 2);
             typedef void (*OvKernel)(OvParams);
             if (legacy) {
-                if (check_spans)
+                if (check_spans && !use_osr)
                     hipLaunchKernelGGL(k_osv_check, dim3((c.ntiles + 255) / 256), dim3(256), 0, stream, q);
                 MGS_HIP(h, hipEventRecord(h->ev0, stream));
+                if (use_osr) {
+                    q.in_bytes = (uint32_t) osr_image_bytes(osr_nq);
+                    static const char *sv = getenv("MGS_OSR_STATS");
+                    if (!osr_launch(q, osr_k, osr_nq, lm, osr_a4, sv && atoi(sv), grid, stream)) {
+                        h->err = "mgs_pack_device: no k_onesweepr instantiation for this call";
+                        return MGS_ERR_ARG;
+                    }
+                }
+                else {
 #define OVK(K, V) {k_onesweepv<kOvThreads, K, V, 4, 8, 0>, k_onesweepv<kOvThreads, K, V, 4, 8, 1>, \
                    k_onesweepv<kOvThreads, K, V, 4, 8, 2>}
                 static const OvKernel kernels[3][3] = {OVK(1, 0), OVK(2, 0), OVK(4, 0)};
 #undef OVK
                 const int ki = ov_k == 1 ? 0 : (ov_k == 2 ? 1 : 2);
                 hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
+                }
                 if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
                 hipLaunchKernelGGL(k_osv_finalize, dim3(1), dim3(64), 0, stream, q);
                 if (sa) {
@@ -934,7 +998,9 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                 h->pending_rounds = max_rounds;
             }
             h->pending_ov_k = ov_k;
+            h->pending_osr = legacy && use_osr;
             h->last_algo = legacy ? "onesweepv" : "onesweepd";
+            h->last_kernel = legacy ? (use_osr ? "k_onesweepr" : "k_onesweepv") : "k_onesweepd";
         }
         if (!osv || may_fall_back) {
         int rc = ensure_generic_scratch(h, d_dest_out == nullptr);
@@ -961,7 +1027,11 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         hipLaunchKernelGGL(k_gen_scatter, dim3(p.ntiles), dim3(GEN_THREADS), 0, stream, p);
         MGS_HIP(h, hipEventRecord(h->ev1, stream));
         hipLaunchKernelGGL(k_gen_finalize, dim3(1), dim3(GEN_THREADS), 0, stream, p);
-        if (!osv) h->last_algo = "generic";
+        if (!osv) {
+            h->last_algo = "generic";
+            h->last_kernel = "k_gen_scatter";
+            h->pending_osr = false;
+        }
         }
     }
     MGS_HIP(h, hipGetLastError());
@@ -1076,6 +1146,9 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
         for (int b = 0; b < P; b++) bytes += out->send_offset[b] - h->pending_init[b];
         if (recs > 0 && bytes > 0 && h->pending_rounds <= 1 && !h->pending_streams) h->ov_bytes_per_record = (double) bytes / (double) recs;
         if (h->pending_osv) h->ov_shrink = 0; // a one-sweep kernel served the call: the length alone decides again
+        // k_onesweepr: more than one record in 64 did not fit its registers -- wider registers from now on
+        if (h->pending_osv && h->pending_osr && recs > 0 && (uint64_t) h->h_ctrl->head.long_records * 64u > recs)
+            h->osr_nq = 2;
     }
     return MGS_OK;
 }

@@ -172,6 +172,7 @@ struct CtrlHead {
     uint32_t fallback;            // byte-granular one-sweep path: 1 = a tile does not fit LDS, run the generic path
     uint32_t rounds_cut;          // round-cutting kernels: round cuts published so far (= index of the last round begun)
     uint32_t f_cuts;              // streams layout: round cuts found by the round finder
+    uint32_t long_records;        // k_onesweepr: records longer than the registers that hold a record
     uint64_t part_base[MGS_MAX_RANKS]; // device address of each partition's byte 0
     int64_t part_cap[MGS_MAX_RANKS];   // capacity in bytes
     int64_t part_init[MGS_MAX_RANKS];  // bytes already there

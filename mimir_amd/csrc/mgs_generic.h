@@ -86,6 +86,7 @@ __device__ inline bool gen_key_len(const mgs_layout &lay, const uint8_t *r,
     return vlen != ~0u && klen + vlen == len;
 }
 
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ __launch_bounds__(GEN_THREADS) void k_gen_hist(GenParams p)
 {
     if (p.gate && p.ctrl->head.fallback == 0) return;
@@ -122,9 +123,11 @@ __global__ __launch_bounds__(GEN_THREADS) void k_gen_hist(GenParams p)
     for (uint32_t b = tid; b < cols; b += GEN_THREADS)
         p.tile_hist[(uint64_t) tile * cols + b] = hist[b];
 }
+#endif
 
 // One block.  Column b < P of tile_base starts at part_init[b]; column P
 // (local-bypass record count) starts at 0.  Row ntiles receives the totals.
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ __launch_bounds__(1024) void k_gen_scan(GenParams p)
 {
     if (p.gate && p.ctrl->head.fallback == 0) return;
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(1024) void k_gen_scan(GenParams p)
     // exactly one chunk per column ends at T and is either non-empty or chunk 0
     if (t1 == T && (t0 < T || c == 0)) p.tile_base[(uint64_t) T * cols + b] = run;
 }
+#endif
 
 __device__ __forceinline__ void copy_record(uint8_t *dst, const uint8_t *src, uint32_t len)
 {
@@ -172,6 +176,7 @@ __device__ __forceinline__ void copy_record(uint8_t *dst, const uint8_t *src, ui
     }
 }
 
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ __launch_bounds__(GEN_THREADS) void k_gen_scatter(GenParams p)
 {
     if (p.gate && p.ctrl->head.fallback == 0) return;
@@ -251,8 +256,10 @@ __global__ __launch_bounds__(GEN_THREADS) void k_gen_scatter(GenParams p)
         }
     }
 }
+#endif
 
 // One block.  Everything before the cut index counts; the rest is ignored.
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ __launch_bounds__(GEN_THREADS) void k_gen_finalize(GenParams p)
 {
     if (p.gate && p.ctrl->head.fallback == 0) return;
@@ -293,6 +300,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_gen_finalize(GenParams p)
         if (p.self < 0) res->local_bytes = 0;
     }
 }
+#endif
 
 } // namespace mgs
 #endif

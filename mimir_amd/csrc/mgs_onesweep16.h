@@ -455,6 +455,7 @@ __global__ __launch_bounds__(THREADS) void k_copy16(const uint4 *in, uint4 *out,
 // One wave.  Computes send_offset[] and the counters at the end of the round:
 // either everything (no record overflowed) or everything before the first
 // record that did not fit, which lies in the lowest tile that reported one.
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ __launch_bounds__(64) void k_os_finalize(OsParams p)
 {
     __shared__ volatile unsigned long long run[OS_MAXP]; // records of the cut tile seen so far, per dest
@@ -540,6 +541,7 @@ __global__ __launch_bounds__(64) void k_os_finalize(OsParams p)
         if (p.self < 0) res->local_bytes = 0;
     }
 }
+#endif
 
 } // namespace mgs
 #endif

@@ -797,6 +797,7 @@ __host__ __device__ inline size_t os_rtab_words(uint32_t max_rounds, uint32_t P)
 // Columns of the chained scan: PC of them, the first P count partition units of
 // 1 << unit_shift bytes; lrec_col counts local-bypass records (for 16-byte records the
 // local partition's own column, else an extra column).
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ __launch_bounds__(256) void k_os_rounds_final(OsParams p, uint32_t P, uint32_t lrec_col,
                                                          unsigned long long *tab)
 {
@@ -846,6 +847,7 @@ __global__ __launch_bounds__(256) void k_os_rounds_final(OsParams p, uint32_t P,
     }
     if (p.clip_out && gtid < PC) p.clip_out[1 + gtid] = end_of(n_rounds - 1, gtid);
 }
+#endif
 
 } // namespace mgs
 #endif

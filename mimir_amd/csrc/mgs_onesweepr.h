@@ -1,0 +1,663 @@
+// k_onesweepr: single-pass stable hash-partition of byte-granular records whose
+// bytes go from global memory straight into registers.
+//
+// Serves the layouts of k_onesweepv's modes 1 and 2 -- ONE string key with a
+// fixed-width or absent value (wordcount, join), and fixed-width keys and values
+// of any width up to 32 bytes (octree level passes) -- with fewer instructions per
+// record: k_onesweepv parks a tile's span in LDS, reads every key from there to
+// hash it, reads every record again to move it into the image and crosses four
+// barriers per tile.  Here
+//
+//   load      lane l owns K consecutive records; each record's first 16 * NQ bytes
+//             are fetched with NQ unaligned 16-byte loads from the record's own
+//             address (neighbouring lanes read neighbouring bytes, so every line is
+//             fetched from HBM once and the rest are hits in the vector cache); the
+//             loads of tile i + 1 and the offsets of tile i + 2 are in flight while
+//             tile i is processed.  No staging buffer, no staging barriers;
+//   hash      lookup3 (src/hash.cpp:152-400) on the key words in registers, masked
+//             to the key's length; a string key's NUL rule (strlen + 1,
+//             src/serializer.h:131-136) from zero-byte flags of the same words;
+//   rank      as in k_onesweepv: emit order in a tile is (wave, lane, k), one wave
+//             scan per pair of destinations over the lanes' byte totals;
+//   reorder   registers -> LDS image grouped by destination (pieces of 16/8/4/2/1
+//             bytes; dwords when every record is a multiple of four bytes long);
+//   chain     the windowed chained scan of mgs_onesweep16w.h over byte counts, run
+//             by a scan wave;
+//   store     one trip later, as k_onesweepv: 16-byte chunks aligned to the global
+//             address of each partition run.
+//
+// Two barriers per tile.  A record longer than its registers (rare by the host's
+// choice of NQ) gets its key hashed and its remaining bytes copied from global
+// memory by its lane, and is counted in Ctrl::head.long_records so that the host can
+// pick wider registers for the next call.  A tile whose bytes do not fit the image
+// raises Ctrl::head.fallback; the host then redoes the call with other kernels.
+#ifndef MGS_ONESWEEPR_H
+#define MGS_ONESWEEPR_H
+
+#include "mgs_onesweepv.h"
+
+namespace mgs {
+
+constexpr int OSR_THREADS = 512;
+constexpr int OSR_LANES = (OSR_THREADS / 64 - 1) * 64; // worker lanes
+constexpr int OSR_IMG1 = 29696;                        // image bytes, NQ = 1: 1792 records of 16 bytes + slack
+constexpr int OSR_IMG2 = 58368;                        // image bytes, NQ = 2: 1792 records of 32 bytes + slack
+
+// The round finder's view of a tile: records read where they lie in global memory.
+struct FinderSrcG {
+    const OvParams &q;
+    __device__ void stage(uint32_t, int, int) {}
+    struct Pre {
+        uint64_t o0, o1;
+    };
+    __device__ Pre fetch(uint32_t tile, uint32_t i, bool &valid) const
+    {
+        const uint64_t T = q.os.tile_records;
+        const uint64_t idx = (uint64_t) tile * T + i;
+        valid = i < T && idx < q.n;
+        Pre f = {0, 0};
+        if (valid) {
+            f.o0 = ov_offset(q, idx);
+            f.o1 = ov_offset(q, idx + 1);
+        }
+        return f;
+    }
+    __device__ void info(const Pre &f, uint32_t &d, uint32_t &u, bool &valid) const
+    {
+        d = 0;
+        u = 0;
+        const uint32_t len = (uint32_t) (f.o1 - f.o0);
+        uint32_t klen = 0;
+        if (f.o1 <= f.o0 || f.o1 - f.o0 > GEN_MAX_RECORD || !gen_key_len(q.lay, q.blob + f.o0, len, klen)) {
+            valid = false; // reported by the sweep
+            return;
+        }
+        d = fastmod(hashlittle_bytes(q.blob + f.o0, klen), q.os.fm);
+        u = len;
+    }
+};
+
+// mask of the first clamp(nb, 0, 4) bytes of a word
+__device__ __forceinline__ uint32_t osr_byte_mask(int32_t nb)
+{
+    return nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+}
+
+// flags (bit 7 of a byte) of the zero bytes of t: exact for the lowest zero byte, and no
+// flag at all when there is none
+__device__ __forceinline__ uint32_t osr_zero_flags(uint32_t t)
+{
+    return (t - 0x01010101u) & ~t & 0x80808080u;
+}
+
+// lookup3 hashlittle (initval 0) of the first klen bytes (1 <= klen <= 4 * NW) of a record
+// held as NW little-endian words.  CSTR: the key is a C string with its NUL -- `ok` is
+// cleared unless the first zero byte of the key is its last byte.
+template <int NW, bool CSTR>
+__device__ __forceinline__ uint32_t osr_hash_words(const uint32_t (&w)[NW], uint32_t klen, bool &ok)
+{
+    uint32_t a, b, c;
+    a = b = c = 0xdeadbeefu + klen;
+    uint32_t zfull = 0;
+#define OSR_W(i) ((i) < NW ? w[(i) < NW ? (i) : 0] : 0u)
+    auto tail = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t rem) { // 1 <= rem <= 12
+        const uint32_t m0 = osr_byte_mask((int32_t) rem), m1 = osr_byte_mask((int32_t) rem - 4),
+                       m2 = osr_byte_mask((int32_t) rem - 8);
+        const uint32_t x0 = w0 & m0, x1 = w1 & m1, x2 = w2 & m2;
+        a += x0;
+        b += x1;
+        c += x2;
+        MGS_FINAL(a, b, c);
+        if (CSTR) {
+            // bytes beyond the key count as non-zero; byte i of word j is bit 8 * i + j of Z
+            const uint32_t Z = (osr_zero_flags(x0 | ~m0) >> 7) | (osr_zero_flags(x1 | ~m1) >> 6)
+                               | (osr_zero_flags(x2 | ~m2) >> 5);
+            const uint32_t last = rem - 1u;
+            ok = ok && Z == (1u << (8u * (last & 3u) + (last >> 2)));
+        }
+    };
+    if (klen <= 12) {
+        tail(OSR_W(0), OSR_W(1), OSR_W(2), klen);
+    }
+    else {
+        a += OSR_W(0);
+        b += OSR_W(1);
+        c += OSR_W(2);
+        MGS_MIX(a, b, c);
+        if (CSTR) zfull = osr_zero_flags(OSR_W(0)) | osr_zero_flags(OSR_W(1)) | osr_zero_flags(OSR_W(2));
+        if (NW > 6 && klen > 24) {
+            a += OSR_W(3);
+            b += OSR_W(4);
+            c += OSR_W(5);
+            MGS_MIX(a, b, c);
+            if (CSTR) zfull |= osr_zero_flags(OSR_W(3)) | osr_zero_flags(OSR_W(4)) | osr_zero_flags(OSR_W(5));
+            tail(OSR_W(6), OSR_W(7), 0u, klen - 24u);
+        }
+        else {
+            tail(OSR_W(3), OSR_W(4), OSR_W(5), klen - 12u);
+        }
+    }
+#undef OSR_W
+    if (CSTR) ok = ok && zfull == 0;
+    return c;
+}
+
+// THREADS = 64 * (workers + 1 scan wave); K records per worker lane; NQ 16-byte register
+// quads per record; LM: 1 = one string key + fixed-width or absent value, 2 = fixed-width
+// key + fixed-width or absent value; A4: every record length, partition base and initial
+// fill is a multiple of four (fixed widths only), so image and partitions are moved as
+// aligned dwords; IMG: bytes of the LDS image.
+template <int THREADS, int K, int NQ, int VAR, int MINW, int LOOK, int LM, bool A4, int IMG>
+__global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
+{
+    static_assert(LM == 1 || LM == 2, "layout modes 1 and 2");
+    static_assert(!A4 || LM == 2, "dword moves need fixed widths");
+    const OsParams &p = q.os;
+    constexpr int WORKERS = THREADS / 64 - 1, WT = WORKERS * 64, T = WT * K;
+    constexpr int NW = 4 * NQ;
+    constexpr uint32_t RB = 16u * NQ; // bytes of a record held in registers
+    __shared__ __attribute__((aligned(16))) uint8_t sout[IMG + 32]; // reads run up to 19 bytes past a run
+    __shared__ uint32_t wcnt[2 * WORKERS * OS_MAXP];                // bytes per (wave, dest), two tiles
+    __shared__ uint32_t wslot[WORKERS * OS_MAXP];                   // first image byte of (wave, dest)
+    __shared__ uint32_t dstart2[2 * OS_MAXP];                       // first image byte of dest, two tiles
+    __shared__ unsigned long long gaddr2[2 * OS_MAXP];              // global address of the run's first byte
+    __shared__ uint32_t nbytes2[2 * OS_MAXP];                       // bytes of the run to store (clipped)
+    __shared__ uint32_t cstart2[2 * (OS_MAXP + 1)];                 // first store unit of dest's run (+ total)
+    __shared__ volatile uint32_t misc[4]; // [0] first tile, [1] second tile / tile after next
+    __shared__ uint32_t arrive[2];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t P = q.P;  // destinations
+    const uint32_t PC = p.P; // chain columns
+
+    if (p.finder && blockIdx.x == 0) {
+        // streams layout: this workgroup finds the rounds instead of sweeping
+        typedef FinderLdsT<T / 64> FL;
+        static_assert(sizeof(FL) <= sizeof(sout), "the finder's tables live in the image buffer");
+        FinderSrcG src{q};
+        os_round_finder<FinderSrcG, THREADS / 64, T / 64>(p, P, src, reinterpret_cast<FL *>(sout), tid);
+        return;
+    }
+
+    for (int j = tid; j < 2 * WORKERS * OS_MAXP; j += THREADS) wcnt[j] = 0;
+    if (tid == 0) {
+        arrive[0] = 0;
+        arrive[1] = 0;
+        misc[0] = atomicAdd(&p.ctrl->head.ticket, 1u);
+        misc[1] = atomicAdd(&p.ctrl->head.ticket, 1u);
+    }
+    __syncthreads();
+    uint32_t tile = misc[0], next = misc[1];
+    int par = 0;
+
+    // ------------------------------------------------------------------ scan wave
+    if (w == WORKERS) {
+        // every later tile waits for this wave's prefix: it goes first at the issue arbiter
+        __builtin_amdgcn_s_setprio(3);
+        OsWalkStats ws;
+        const bool live = (uint32_t) lane < PC, is_dest = (uint32_t) lane < P;
+        const unsigned long long my_base = is_dest ? p.ctrl->head.part_base[lane] : 0ull;
+        const unsigned long long my_cap = is_dest ? (unsigned long long) p.ctrl->head.part_cap[lane] : 0ull;
+        while (tile < p.ntiles) {
+            const uint32_t *wc = wcnt + par * (WORKERS * OS_MAXP);
+            __syncthreads(); // A: counts(tile) complete
+            uint32_t tot = 0; // lane = destination, bytes
+#pragma unroll
+            for (int ww = 0; ww < WORKERS; ww++) tot += wc[ww * OS_MAXP + lane];
+            unsigned long long acc = 0;
+            if (tile == 0) {
+                acc = is_dest ? (unsigned long long) p.ctrl->head.part_init[lane] : 0ull;
+                if (live) os_store_status(p.status + lane, OS_FLAG_INCL | (acc + tot));
+            }
+            // the tile after next: drawn two trips ahead so that the workers can fetch a
+            // tile's offsets one trip before its bytes
+            if (lane == 0) misc[1] = atomicAdd(&p.ctrl->head.ticket, 1u);
+            for (int j = lane; j < WORKERS * OS_MAXP; j += 64) wcnt[(par ^ 1) * (WORKERS * OS_MAXP) + j] = 0;
+            if (lane == 0) arrive[par ^ 1] = 0;
+            __syncthreads(); // B
+            const uint32_t next2 = misc[1];
+            if ((VAR & OSV_FAKE_CHAIN) && tile != 0) { // timing only: made-up positions, no scan
+                acc = (unsigned long long) tile * 3600ull;
+            }
+            else if (tile != 0) {
+                acc = os_window_walk<VAR, LOOK>(p, tile, lane, &ws);
+                if (live)
+                    os_store_status(p.status + (uint64_t) tile * PC + lane,
+                                    OS_FLAG_INCL | ((acc + tot) & OS_VALUE_MASK));
+            }
+            // what the workers need to store this tile's image one trip from now
+            const unsigned long long avail = acc < my_cap ? my_cap - acc : 0ull;
+            const uint32_t nb = is_dest ? (uint32_t) min((unsigned long long) tot, avail) : 0u;
+            if (is_dest && nb < tot) {
+                if ((int32_t) lane == p.self) raise_error(p.ctrl, MGS_ERR_LOCAL_OVERFLOW);
+                else atomicMin(&p.ctrl->head.cut_tile, tile);
+            }
+            const unsigned long long G = my_base + acc;
+            // work units of the store: (destination, block of 64 chunks of its run)
+            const uint32_t nch = nb ? (uint32_t) (((G & 15ull) + nb + 15ull) >> 4) : 0u;
+            const uint32_t units = (nch + 63u) >> 6;
+            const uint32_t uincl = wave_incl_scan_u32(units, lane);
+            gaddr2[par * OS_MAXP + lane] = G;
+            nbytes2[par * OS_MAXP + lane] = nb;
+            cstart2[par * (OS_MAXP + 1) + lane] = uincl - units;
+            if (lane == 63) cstart2[par * (OS_MAXP + 1) + OS_MAXP] = uincl;
+            tile = next;
+            next = next2;
+            par ^= 1;
+        }
+        __syncthreads(); // matches the workers' last barrier
+        if ((VAR & OSV_STATS) && lane == 0) ws.flush(p.ctrl);
+        return;
+    }
+
+    // ------------------------------------------------------------------- workers
+    const int wt = w * 64 + lane; // worker thread index: owns records wt*K .. wt*K+K-1 of a tile
+    uint32_t len[K];              // record k: length (0 = no record)
+    uint32_t rw[K][NW];           // its first RB bytes
+    uint32_t roff[K];             // its byte offset from blob + cur_base (records longer than RB read the rest there)
+    uint64_t cur_base = 0;
+
+    // A zero the compiler cannot see through: an index that is the same in every lane
+    // would be fetched with a scalar load, and scalar loads share their completion
+    // counter with LDS, out of order -- every later wait for an LDS access would then
+    // also wait out the round trip to memory.
+    uint32_t vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    // first byte behind the call's records: no load may reach beyond it
+    const uint64_t end_abs = q.rec_off ? (uint64_t) q.rec_off[q.first + q.n + vzero]
+                                       : (q.first + q.n) * (uint64_t) q.fixed_len;
+
+    // Offsets of a tile's records as fetched: K+1 record boundaries of this lane plus the
+    // tile's two ends, as 32-bit values relative to `base` (the offset array's own values
+    // with base 0, or multiples of the fixed width with base = the tile's first byte).
+    struct Offsets {
+        uint64_t base;
+        uint32_t rec[K + 1], s, e;
+        uint32_t nrec; // records of the tile
+    };
+    auto fetch_offsets = [&](uint32_t t, Offsets &f) {
+        const uint64_t i0 = (uint64_t) t * T, i1 = min(q.n, i0 + T);
+        f.nrec = (uint32_t) (i1 - i0);
+        if (q.rec_off) {
+            const uint32_t *ro = q.rec_off + q.first;
+            f.base = 0;
+            f.s = ro[i0 + vzero];
+            f.e = ro[i1 + vzero];
+#pragma unroll
+            for (int k = 0; k <= K; k++) f.rec[k] = ro[min(i1, i0 + (uint64_t) wt * K + k)];
+        }
+        else {
+            f.base = (q.first + i0) * (uint64_t) q.fixed_len;
+            f.s = 0;
+            f.e = (uint32_t) (i1 - i0) * q.fixed_len;
+#pragma unroll
+            for (int k = 0; k <= K; k++)
+                f.rec[k] = (uint32_t) (min(i1, i0 + (uint64_t) wt * K + k) - i0) * q.fixed_len;
+        }
+    };
+    // May record k of the tile be fetched with whole 16-byte loads?  It must exist, lie inside
+    // the tile's span, and its RB bytes must end inside the call's records.
+    auto quad_ok = [&](const Offsets &f, int k) -> bool {
+        return f.rec[k + 1] > f.rec[k] && f.rec[k] >= f.s && f.rec[k + 1] <= f.e && f.e >= f.s
+               && f.base + f.rec[k] + RB <= end_abs;
+    };
+    // Issue the loads of a tile's records (nothing is computed from the loaded values here).
+    auto issue_loads = [&](const Offsets &f, uint32_t (&r)[K][NW]) {
+        const uint8_t *tb = q.blob + f.base;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool okq = quad_ok(f, k);
+#pragma unroll
+            for (int j = 0; j < NQ; j++) {
+                OvU128 v = {0, 0, 0, 0};
+                if (okq) v = *reinterpret_cast<const OvU128 *>(tb + f.rec[k] + 16u * j);
+                r[k][4 * j + 0] = v.x;
+                r[k][4 * j + 1] = v.y;
+                r[k][4 * j + 2] = v.z;
+                r[k][4 * j + 3] = v.w;
+            }
+        }
+    };
+    // Lengths and checks of a tile's records; the few records next to the end of the call
+    // (quad_ok said no) are fetched byte by byte.
+    auto settle = [&](const Offsets &f, uint32_t (&r)[K][NW]) {
+        const bool fits = f.e >= f.s && f.e - f.s <= (uint32_t) IMG;
+        cur_base = f.base;
+        if (!fits) // the tile's bytes do not fit the image: the host redoes the call with other kernels
+            __hip_atomic_store(&p.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t l = f.rec[k + 1] - f.rec[k]; // wraps to a huge value when not monotonic
+            len[k] = fits ? l : 0u;
+            roff[k] = f.rec[k];
+            if (l == 0) { // past the end of the call -- or an empty record, which no layout produces
+                if ((uint32_t) (wt * K + k) < f.nrec) raise_error(p.ctrl, MGS_ERR_MALFORMED);
+                continue;
+            }
+            if (l > GEN_MAX_RECORD || f.rec[k] < f.s || f.rec[k + 1] > f.e || f.rec[k + 1] < f.rec[k]) {
+                raise_error(p.ctrl, MGS_ERR_MALFORMED);
+                len[k] = 0;
+                continue;
+            }
+            if (fits && !quad_ok(f, k)) {
+                const uint8_t *src = q.blob + f.base + f.rec[k];
+                const uint32_t nbytes = l < RB ? l : RB;
+#pragma unroll
+                for (int j = 0; j < NW; j++) r[k][j] = 0;
+                for (uint32_t i = 0; i < nbytes; i++) {
+                    const uint32_t v = (uint32_t) src[i] << (8u * (i & 3u));
+#pragma unroll
+                    for (int j = 0; j < NW; j++)
+                        if ((i >> 2) == (uint32_t) j) r[k][j] |= v;
+                }
+            }
+        }
+    };
+    // Stream out the image of a tile (parity pr).  A wave takes one unit at a time: 64
+    // consecutive 16-byte chunks of one destination's run, so everything but the chunk
+    // index is the same in all its lanes.
+    auto store_image = [&](int pr) {
+        const uint32_t *ustart = cstart2 + pr * (OS_MAXP + 1);
+        const uint32_t utotal = ustart[OS_MAXP];
+        const uint32_t my_ustart = ustart[lane]; // lane = destination; non-decreasing, total from P on
+        for (uint32_t u = (uint32_t) w; u < utotal; u += WORKERS) {
+            const uint32_t b = (uint32_t) __popcll(__ballot(my_ustart <= u)) - 1u; // last dest starting at or before u
+            const uint32_t u0 = (uint32_t) __builtin_amdgcn_readlane((int) my_ustart, (int) b);
+            const unsigned long long G = gaddr2[pr * OS_MAXP + b];
+            const uint32_t nb = nbytes2[pr * OS_MAXP + b];
+            const uint32_t ds = dstart2[pr * OS_MAXP + b]; // image byte of global byte G
+            const uint32_t a = (uint32_t) G & 15u;         // the run starts `a` bytes into its first chunk
+            const uint32_t off = ((u - u0) * 64u + (uint32_t) lane) << 4; // this lane's chunk, from the aligned start
+            // whole chunks only; the partial chunks at the two ends of the runs follow below
+            if (off >= a && off + 16u <= a + nb) {
+                uint4 val;
+                if (A4) {
+                    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(sout + (ds + off - a));
+                    val = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+                }
+                else {
+                    val = ov_lds_read16(sout, ds + off - a);
+                }
+                *reinterpret_cast<uint4 *>((G - a) + off) = val;
+            }
+        }
+        // The partial chunks (at most two per destination): one wave, lane = (destination,
+        // end), so that the divergent byte work runs once per tile and not once per unit.
+        if (w != WORKERS - 1) return;
+        for (uint32_t it = (uint32_t) lane; it < 2u * P; it += 64u) {
+            const uint32_t b = it >> 1;
+            const unsigned long long G = gaddr2[pr * OS_MAXP + b];
+            const uint32_t nb = nbytes2[pr * OS_MAXP + b];
+            if (nb == 0) continue;
+            const uint32_t nch = (uint32_t) (((G & 15ull) + nb + 15ull) >> 4);
+            if ((it & 1u) && nch == 1) continue; // the only chunk is taken as the first
+            const unsigned long long g0 = (G & ~15ull) + ((it & 1u) ? (unsigned long long) (nch - 1u) << 4 : 0ull);
+            if (g0 >= G && g0 + 16 <= G + nb) continue; // a whole chunk: stored above
+            // naturally aligned pieces, growing from the first byte, then shrinking towards the last
+            const uint8_t *src0 = sout + dstart2[pr * OS_MAXP + b];
+            unsigned long long ga = g0 > G ? g0 : G;
+            const unsigned long long gb = g0 + 16 < G + nb ? g0 + 16 : G + nb;
+            if ((ga & 1) && ga + 1 <= gb) {
+                *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
+                ga += 1;
+            }
+            if ((ga & 2) && ga + 2 <= gb) {
+                *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
+                ga += 2;
+            }
+            if ((ga & 4) && ga + 4 <= gb) {
+                *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
+                ga += 4;
+            }
+            if (ga + 8 <= gb) {
+                *reinterpret_cast<unsigned long long *>(ga) = reinterpret_cast<const OvU64 *>(src0 + (ga - G))->v;
+                ga += 8;
+            }
+            if (ga + 4 <= gb) {
+                *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
+                ga += 4;
+            }
+            if (ga + 2 <= gb) {
+                *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
+                ga += 2;
+            }
+            if (ga + 1 <= gb) *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
+        }
+    };
+    // n <= 16 bytes out of four registers to any address of the image
+    auto put = [&](uint8_t *o, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t n) {
+        if (n >= 16) {
+            *reinterpret_cast<OvU128 *>(o) = OvU128{a0, a1, a2, a3};
+            return;
+        }
+        if (n & 8u) {
+            reinterpret_cast<OvU64 *>(o)->v = (unsigned long long) a0 | ((unsigned long long) a1 << 32);
+            a0 = a2;
+            a1 = a3;
+            o += 8;
+        }
+        if (n & 4u) {
+            reinterpret_cast<OvU32 *>(o)->v = a0;
+            a0 = a1;
+            o += 4;
+        }
+        if (n & 2u) {
+            reinterpret_cast<OvU16 *>(o)->v = (uint16_t) a0;
+            a0 >>= 16;
+            o += 2;
+        }
+        if (n & 1u) *o = (uint8_t) a0;
+    };
+
+    Offsets fn; // offsets of the tile after the current one: fetched one whole trip before its bytes
+    fn.base = 0;
+    fn.s = fn.e = 0;
+    fn.nrec = 0;
+#pragma unroll
+    for (int k = 0; k <= K; k++) fn.rec[k] = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        len[k] = 0;
+        roff[k] = 0;
+    }
+    if (tile < p.ntiles) {
+        Offsets f0;
+        fetch_offsets(tile, f0);
+        if (next < p.ntiles) fetch_offsets(next, fn);
+        issue_loads(f0, rw);
+        settle(f0, rw);
+    }
+    bool have_prev = false;
+    const uint32_t vlen = (q.lay.val_kind == MGS_VAL_FIXED) ? (uint32_t) q.lay.val_bytes : 0u;
+
+    while (tile < p.ntiles) {
+        uint32_t *wc = wcnt + par * (WORKERS * OS_MAXP);
+        // ---- hash: destination of each of this lane's records
+        uint32_t d[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            d[k] = 0xFFu;
+            if (len[k] == 0) continue;
+            uint32_t hk = 0;
+            uint32_t klen;
+            bool ok;
+            if (LM == 1) {
+                klen = len[k] - vlen;
+                ok = len[k] > vlen;
+            }
+            else {
+                klen = (uint32_t) q.lay.key_bytes;
+                ok = klen <= len[k];
+            }
+            if (ok && klen <= RB) {
+                hk = osr_hash_words<NW, LM == 1>(rw[k], klen, ok);
+            }
+            else if (ok) {
+                // a key longer than the registers hold: from global memory, byte by byte
+                const uint8_t *r = q.blob + cur_base + roff[k];
+                if (LM == 1) {
+                    ok = r[klen - 1] == 0;
+                    for (uint32_t j = 0; j + 1 < klen; j++) ok = ok && r[j] != 0;
+                }
+                hk = hashlittle_bytes(r, klen);
+            }
+            if (!ok) {
+                raise_error(p.ctrl, MGS_ERR_MALFORMED);
+                len[k] = 0;
+                continue;
+            }
+            d[k] = p.fm.pow2 ? fastmod_pow2(hk, p.fm) : fastmod_magic(hk, p.fm);
+        }
+        if (p.dest_out) {
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (len[k]) p.dest_out[(uint64_t) tile * T + (uint64_t) wt * K + k] = (uint8_t) d[k];
+        }
+        // ---- rank: byte position of each record inside the wave's share of its destination.
+        // Two destinations share one scan: 16-bit fields (a wave's bytes fit: the tile's
+        // bytes fit the image).
+        uint32_t pw[K], field[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            pw[k] = 0;
+            field[k] = len[k] << (16 * (d[k] & 1u)); // this record's bytes in its destination's field
+        }
+        for (uint32_t b2 = 0; b2 < (P + 1) / 2; b2++) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) mine += ((d[k] >> 1) == b2) ? field[k] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(mine, lane);
+            uint32_t run = incl - mine;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if ((d[k] >> 1) == b2) {
+                    pw[k] = (run >> (16 * (d[k] & 1u))) & 0xffffu;
+                    run += field[k];
+                }
+            }
+            if (lane == 63) {
+                wc[w * OS_MAXP + 2 * b2] = incl & 0xffffu;
+                wc[w * OS_MAXP + 2 * b2 + 1] = incl >> 16;
+            }
+        }
+        if (p.self >= 0) { // chain column P: records of the local-bypass destination
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) cnt += (uint32_t) __popcll(__ballot(d[k] == (uint32_t) p.self));
+            if (lane == 63) wc[w * OS_MAXP + P] = cnt;
+        }
+        {
+            // the last worker wave to get here publishes the tile's byte counts
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            uint32_t arrived = 0;
+            if (lane == 0) arrived = atomicAdd(&arrive[par], 1u);
+            arrived = __builtin_amdgcn_readfirstlane(arrived);
+            if (arrived == (uint32_t) WORKERS - 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                uint32_t tot_all = 0;
+#pragma unroll
+                for (int ww = 0; ww < WORKERS; ww++)
+                    tot_all += ((volatile uint32_t *) wc)[ww * OS_MAXP + lane];
+                os_publish_agg16(p, tile, lane, tot_all);
+            }
+        }
+        __syncthreads(); // A: counts(tile) complete; tables of the previous tile are ready
+        // the phases that issue memory operations go before the other waves' hashing
+        __builtin_amdgcn_s_setprio(1);
+
+        uint32_t tot = 0, below = 0; // lane = destination
+#pragma unroll
+        for (int ww = 0; ww < WORKERS; ww++) {
+            const uint32_t v = wc[ww * OS_MAXP + lane];
+            tot += v;
+            if (ww < w) below += v;
+        }
+        if ((uint32_t) lane >= P) tot = 0; // the record-count column takes no image space
+        const uint32_t first_byte = wave_incl_scan_u32(tot, lane) - tot;
+        wslot[w * OS_MAXP + lane] = first_byte + below;
+        if (w == 0) dstart2[par * OS_MAXP + lane] = first_byte;
+        if (have_prev) store_image(par ^ 1);
+        __syncthreads(); // B: the image is free
+        const uint32_t next2 = misc[1];
+
+        // offsets of the tile after the next: in flight during the reorder
+        Offsets fn2;
+        fn2.base = 0;
+        fn2.s = fn2.e = 0;
+        fn2.nrec = 0;
+#pragma unroll
+        for (int k = 0; k <= K; k++) fn2.rec[k] = 0;
+        if (next2 < p.ntiles) fetch_offsets(next2, fn2);
+        {
+            // reorder: where every record goes (reads), then the writes out of registers
+            uint32_t dst[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) dst[k] = wslot[w * OS_MAXP + (len[k] ? d[k] : 0u)] + pw[k];
+            if (A4) {
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (len[k] == 0) continue;
+                    uint32_t *o = reinterpret_cast<uint32_t *>(sout + dst[k]);
+#pragma unroll
+                    for (int j = 0; j < NW; j++)
+                        if ((uint32_t) (4 * j) < len[k]) o[j] = rw[k][j];
+                }
+            }
+            else {
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (len[k] == 0) continue;
+                    put(sout + dst[k], rw[k][0], rw[k][1], rw[k][2], rw[k][3], len[k]);
+                }
+                if (NQ > 1) {
+                    bool more = false;
+#pragma unroll
+                    for (int k = 0; k < K; k++) more |= len[k] > 16;
+                    if (__any(more)) {
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            if (len[k] <= 16) continue;
+                            put(sout + dst[k] + 16, rw[k][NW - 4], rw[k][NW - 3], rw[k][NW - 2], rw[k][NW - 1], len[k] - 16);
+                        }
+                    }
+                }
+            }
+            // records longer than their registers: the rest from global memory, byte by byte
+            bool longer = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) longer |= len[k] > RB;
+            if (__any(longer)) {
+                uint32_t nlong = 0;
+                for (int k = 0; k < K; k++) { // not unrolled: rare
+                    if (len[k] <= RB) continue;
+                    nlong++;
+                    const uint8_t *src = q.blob + cur_base + roff[k];
+                    uint8_t *o = sout + dst[k];
+                    for (uint32_t j = RB; j < len[k]; j++) o[j] = src[j];
+                }
+                if (nlong) atomicAdd(&p.ctrl->head.long_records, nlong);
+            }
+        }
+        // the registers are free again: the records of the next tile (its offsets arrived
+        // during the last trip); the other waves' work covers the round trip
+        if (next < p.ntiles) {
+            issue_loads(fn, rw);
+            settle(fn, rw);
+        }
+        else {
+#pragma unroll
+            for (int k = 0; k < K; k++) len[k] = 0;
+        }
+        fn = fn2;
+        __builtin_amdgcn_s_setprio(0);
+        have_prev = true;
+        tile = next;
+        next = next2;
+        par ^= 1;
+    }
+    __syncthreads(); // tables of the last tile are ready
+    if (have_prev) store_image(par ^ 1);
+}
+
+} // namespace mgs
+#endif

@@ -173,6 +173,7 @@ __device__ __forceinline__ void ov_raw_barrier()
 }
 
 // Does every tile's span fit the staging buffer?  One thread per tile.
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ void k_osv_check(OvParams q)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,6 +185,7 @@ __global__ void k_osv_check(OvParams q)
     if (e < s || e - s + shift > (uint64_t) q.in_bytes)
         __hip_atomic_store(&q.os.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#endif
 
 // The round finder's view of a tile of byte-granular records (mgs_round_finder.h): the
 // tile's span is parked in the staging buffer, key lengths and hashes are read from there.
@@ -780,6 +782,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
 // One wave.  send_offset[] / counts at the point where the round ended; when a
 // tile was clipped, re-walk that tile record by record to find the first record
 // that does not fit (src/collectiveshuffler.h:148-160).
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ __launch_bounds__(64) void k_osv_finalize(OvParams q)
 {
     const OsParams &p = q.os;
@@ -894,6 +897,7 @@ __global__ __launch_bounds__(64) void k_osv_finalize(OvParams q)
         res->local_bytes = 0;
     }
 }
+#endif
 
 } // namespace mgs
 #endif

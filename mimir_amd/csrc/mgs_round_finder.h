@@ -337,6 +337,7 @@ __host__ __device__ inline size_t os_stab_words(uint32_t max_rounds, uint32_t P)
 // were packed and the totals at that point): which of the finder's rounds were packed, and
 // the per-round arrays.  A round that begins at or after the first record that was not
 // packed is not reported; the last reported round is open.
+#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
 __global__ __launch_bounds__(256) void k_os_streams_final(OsParams p, uint32_t P, uint32_t lrec_col,
                                                           unsigned long long *tab)
 {
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(256) void k_os_streams_final(OsParams p, uint32_t P
         tab[4] = lbytes;
     }
 }
+#endif
 
 } // namespace mgs
 #endif

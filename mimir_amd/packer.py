@@ -114,6 +114,10 @@ class DevicePacker:
     def last_algo(self):
         return self.lib.mgs_last_algo(self.h).decode()
 
+    def last_kernel(self):
+        """Name of the dominant kernel of the last pack call."""
+        return self.lib.mgs_last_kernel(self.h).decode()
+
     def last_kernel_ms(self):
         """Device time of the dominant kernel of the last completed call."""
         ms = C.c_float()
