@@ -17,6 +17,7 @@
 #include "mgs_onesweepv.h"
 #include "mgs_onesweepd.h"
 #include "mgs_onesweepr_api.h"
+#include "mgs_kernel_tables.h"
 #include "mgs_unpack.h"
 #include "mgs_tokenize.h"
 #include "mgs_group.h"
@@ -92,38 +93,14 @@ static hipError_t noalloc_scratch_for(int device, unsigned char **out)
     return hipSuccess;
 }
 
-// Instantiations of the one-sweep kernel.  kDefaultOsVariant is what production
-// calls run; the rest are there to be timed against it (mgs_set_tuning,
-// tools/tune_onesweep.py): each prices one design decision on the hardware.
-typedef void (*OsKernel)(OsParams);
-struct OsVariant {
-    const char *name;
-    int threads, items, blocks_per_cu, tile;
-    bool agg16;         // uses the 16-bit count array of the windowed scan
-    OsKernel kernel[7]; // by number of destination bits (1..6); [0] unused
-};
-#define MINW_(T, B) ((B * (T / 64) + 3) / 4)
-#define SAME7(k) {k, k, k, k, k, k, k}
-#define OSV(name, T, I, V, B) {name, T, I, B, T * I, false, SAME7((k_onesweep16<T, I, V, MINW_(T, B)>))}
-#define OSQ(name, T, I, V, B, L)                                                                    \
-    {name, T, I, B, (T / 64 - 1) * 64 * I, true,                                                    \
-     {nullptr, k_onesweep16q<T, I, V, MINW_(T, B), L, 1>, k_onesweep16q<T, I, V, MINW_(T, B), L, 2>, \
-      k_onesweep16q<T, I, V, MINW_(T, B), L, 3>, k_onesweep16q<T, I, V, MINW_(T, B), L, 4>,          \
-      k_onesweep16q<T, I, V, MINW_(T, B), L, 5>, k_onesweep16q<T, I, V, MINW_(T, B), L, 6>}}
-static const OsVariant kOsVariants[] = {
-    OSQ("q512x8-w8", 512, 8, OSV_EARLY_AGG, 2, 8),                      // 0: production
-    OSQ("q512x8-w8-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2, 8),
-    OSQ("q512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2, 8),              // 2
-    OSQ("q512x8-w4", 512, 8, OSV_EARLY_AGG, 2, 4),
-    OSQ("q512x8-w12", 512, 8, OSV_EARLY_AGG, 2, 12),                    // 4
-    OSQ("q512x8-w12-stats", 512, 8, OSV_EARLY_AGG | OSV_STATS, 2, 12),
-    OSQ("q512x8-w8-late", 512, 8, 0, 2, 8),                             // 6: counts published by the scan wave
-    OSQ("q512x8-w8-late-stats", 512, 8, OSV_STATS, 2, 8),
-    OSV("t512x8", 512, 8, 0, 2),                            // 8: LDS image, every wave works, wave 0 walks
-    OSV("t512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
-    OSV("t512x8-stats", 512, 8, OSV_STATS, 2),              // 10
-};
-constexpr int kNumOsVariants = (int) (sizeof(kOsVariants) / sizeof(kOsVariants[0]));
+static const OsVariant *const kOsVariants = os16_variants(nullptr);
+static int num_os_variants()
+{
+    int n = 0;
+    os16_variants(&n);
+    return n;
+}
+#define kNumOsVariants (num_os_variants())
 constexpr int kDefaultOsVariant = 0;
 
 struct mgs_handle {
@@ -172,7 +149,6 @@ struct mgs_handle {
     int ov_k = 4;             // (unused) records per worker lane of the last variable-width call
     double ov_bytes_per_record = 16.0; // variable width: average record length seen last
     int ov_shrink = 0;        // ... and how much smaller than that length suggests the tile must be
-    int osr_nq = 0;           // k_onesweepr, variable width: register quads per record (0: not chosen yet)
     bool pending_osr = false; // the call in flight runs k_onesweepr
     const char *last_kernel = "none";
     int pending_ov_k = 4;
@@ -493,16 +469,21 @@ static bool osr_enabled(const mgs_handle *h)
     return (h->desc.flags & MGS_FLAG_OSV_STAGED_KERNEL) == 0;
 }
 // Records per lane and register quads for records of about `bytes_per_record` bytes (variable
-// width: 1.25 times the average seen), given the quads the handle has settled on (0: none yet).
-static bool osr_pick(int lm, bool a4, double bytes_per_record, int nq_hint, int shrink, int *k_out, int *nq_out)
+// width: 1.25 times the average seen).  The order is the order of preference measured on
+// MI355X: fixed widths above 16 bytes and string keys with few records per lane run fastest
+// with three records per lane and early requests, string keys otherwise with four.
+static bool osr_pick(int lm, bool a4, double bytes_per_record, int shrink, int *k_out, int *nq_out)
 {
-    static const int cand[4][2] = {{4, 1}, {4, 2}, {2, 2}, {1, 2}};
+    static const int fixed_order[3][2] = {{4, 1}, {3, 2}, {4, 2}};
+    static const int cstr_order[4][2] = {{4, 2}, {3, 2}, {2, 2}, {1, 2}};
+    const int(*cand)[2] = lm == 2 ? fixed_order : cstr_order;
+    const int ncand = lm == 2 ? 3 : 4;
     int skipped = 0;
-    for (const auto &c : cand) {
-        const int k = c[0], nq = c[1];
-        if (nq < nq_hint || !osr_has(k, nq, lm, a4)) continue;
+    for (int i = 0; i < ncand; i++) {
+        const int k = cand[i][0], nq = cand[i][1];
+        if (!osr_has(k, nq, lm, a4)) continue;
         if ((double) (kOvLanes * k) * bytes_per_record > (double) osr_image_bytes(nq)) continue;
-        if (nq == 1 && bytes_per_record > 16.0 * 1.25) continue;
+        if (nq == 1 && bytes_per_record > 16.0) continue;
         if (skipped++ < shrink) continue; // a tile of this size did not fit last time
         *k_out = k;
         *nq_out = nq;
@@ -510,6 +491,9 @@ static bool osr_pick(int lm, bool a4, double bytes_per_record, int nq_hint, int 
     }
     return false;
 }
+// String keys: below this average record length the staged kernel (k_onesweepv) is the faster one
+// (measured: 15-byte wordcount records 0.34 against 0.31 of HBM, 22-byte join records 0.36 against 0.40).
+constexpr double kOsrMinCstrBytes = 18.0;
 
 // Enqueue one pack call.  noalloc: the control block and the chained-scan arrays live
 // in the device's static scratch array, nothing is allocated, only the one-sweep
@@ -650,13 +634,25 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             osr_a4 = (h->fixed_len % 4) == 0 && ((uintptr_t) d_send_image % 4) == 0 && (part_cap % 4) == 0
                      && (D.rank < 0 || ((uintptr_t) d_local_out % 4) == 0);
             for (int b = 0; b < P && osr_a4; b++) osr_a4 = (h->pending_init[b] % 4) == 0;
-            use_osr = h->fixed_len <= 32 && osr_pick(ov_lm, osr_a4, (double) h->fixed_len, 0, 0, &osr_k, &osr_nq);
+            // (the kernel hashes a fixed-width key out of a record's first 16 bytes)
+            use_osr = h->fixed_len <= 32 && LY.key_bytes <= 16
+                      && osr_pick(ov_lm, osr_a4, (double) h->fixed_len, 0, &osr_k, &osr_nq);
         }
         else {
-            if (h->osr_nq == 0) h->osr_nq = h->ov_bytes_per_record <= 14.5 ? 1 : 2;
-            use_osr = osr_pick(ov_lm, false, 1.25 * h->ov_bytes_per_record, h->osr_nq, h->ov_shrink, &osr_k, &osr_nq);
+            static const char *force = getenv("MGS_OSR_FORCE"); // experiments: whatever the record length
+            use_osr = (h->ov_bytes_per_record >= kOsrMinCstrBytes || (force && atoi(force)))
+                      && osr_pick(ov_lm, false, 1.25 * h->ov_bytes_per_record, h->ov_shrink, &osr_k, &osr_nq);
         }
-        if (use_osr) ov_k = osr_k;
+        if (use_osr) {
+            // experiments: pin the instantiation (records per lane, register quads)
+            static const char *ek = getenv("MGS_OSR_K"), *eq = getenv("MGS_OSR_NQ");
+            const int k2 = ek ? atoi(ek) : osr_k, nq2 = eq ? atoi(eq) : osr_nq;
+            if ((ek || eq) && osr_has(k2, nq2, ov_lm, osr_a4)) {
+                osr_k = k2;
+                osr_nq = nq2;
+            }
+            ov_k = osr_k;
+        }
     }
     if (algo == MGS_ALGO_AUTO)
         algo = os_ok ? MGS_ALGO_ONESWEEP16 : (ov_ok ? MGS_ALGO_ONESWEEPV : MGS_ALGO_GENERIC);
@@ -899,7 +895,6 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             const mgs_layout &L = D.layout;
             // layout mode 1: ONE string key and a fixed-width or absent value
             const int lm = (L.val_kind == MGS_VAL_CSTR) ? 0 : (L.key_kind == MGS_KEY_CSTR ? (L.key_count == 1 ? 1 : 0) : 2);
-            typedef void (*OvKernel)(OvParams);
             if (legacy) {
                 if (check_spans && !use_osr)
                     hipLaunchKernelGGL(k_osv_check, dim3((c.ntiles + 255) / 256), dim3(256), 0, stream, q);
@@ -907,18 +902,16 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                 if (use_osr) {
                     q.in_bytes = (uint32_t) osr_image_bytes(osr_nq);
                     static const char *sv = getenv("MGS_OSR_STATS");
-                    if (!osr_launch(q, osr_k, osr_nq, lm, osr_a4, sv && atoi(sv), grid, stream)) {
+                    static const char *pv = getenv("MGS_OSR_PRE"); // experiments: pin early / late requests
+                    static const char *fv = getenv("MGS_OSR_FAKECHAIN"); // timing only, wrong output
+                    const int var = (sv && atoi(sv)) ? OSV_STATS : ((fv && atoi(fv)) ? OSV_FAKE_CHAIN : 0);
+                    if (!osr_launch(q, osr_k, osr_nq, lm, osr_a4, pv ? atoi(pv) : -1, var, grid, stream)) {
                         h->err = "mgs_pack_device: no k_onesweepr instantiation for this call";
                         return MGS_ERR_ARG;
                     }
                 }
                 else {
-#define OVK(K, V) {k_onesweepv<kOvThreads, K, V, 4, 8, 0>, k_onesweepv<kOvThreads, K, V, 4, 8, 1>, \
-                   k_onesweepv<kOvThreads, K, V, 4, 8, 2>}
-                static const OvKernel kernels[3][3] = {OVK(1, 0), OVK(2, 0), OVK(4, 0)};
-#undef OVK
-                const int ki = ov_k == 1 ? 0 : (ov_k == 2 ? 1 : 2);
-                hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
+                    osv_launch(q, ov_k, lm, grid, stream);
                 }
                 if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
                 hipLaunchKernelGGL(k_osv_finalize, dim3(1), dim3(64), 0, stream, q);
@@ -953,25 +946,10 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                 MGS_HIP(h, hipMemsetAsync(c.rt, 0, ((size_t) max_rounds + 1) * ((size_t) columns + 1) * sizeof(unsigned long long), stream));
                 if (check_spans) {
                     const uint64_t items = (uint64_t) c.ntiles * (kOvThreads / 64 - 1);
-                    hipLaunchKernelGGL(k_osd_check, dim3((unsigned) ((items + 255) / 256)), dim3(256), 0, stream, q,
-                                       (uint32_t) (64 * ov_k), (uint32_t) (kOvThreads / 64 - 1));
+                    (void) items;
+                    osd_check_launch(q, (uint32_t) (64 * ov_k), (uint32_t) (kOvThreads / 64 - 1), c.ntiles, stream);
                 }
                 MGS_HIP(h, hipEventRecord(h->ev0, stream));
-#define ODKL(K, V, L) {k_onesweepd<kOvThreads, K, V, 4, L, 0>, k_onesweepd<kOvThreads, K, V, 4, L, 1>, \
-                       k_onesweepd<kOvThreads, K, V, 4, L, 2>}
-#define ODK(K, V) ODKL(K, V, 8)
-                static const OvKernel kernels[25][3] = {ODK(1, 0), ODK(2, 0), ODK(3, 0), ODK(4, 0), ODK(4, OSV_FAKE_CHAIN),
-                                                        ODK(1, OSV_NT_LOAD), ODK(2, OSV_NT_LOAD), ODK(3, OSV_NT_LOAD),
-                                                        ODK(4, OSV_NT_LOAD), ODK(1, OSV_STATS), ODK(2, OSV_STATS),
-                                                        ODK(3, OSV_STATS), ODK(4, OSV_STATS),
-                                                        ODK(1, OSV_STATS | OSV_NO_PREFETCH), ODK(2, OSV_STATS | OSV_NO_PREFETCH),
-                                                        ODK(3, OSV_STATS | OSV_NO_PREFETCH), ODK(4, OSV_STATS | OSV_NO_PREFETCH),
-                                                        // experiments: a wider window of the chained scan
-                                                        ODKL(1, 0, 16), ODKL(2, 0, 16), ODKL(3, 0, 16), ODKL(4, 0, 16),
-                                                        ODKL(1, OSV_STATS | OSV_NO_PREFETCH, 16), ODKL(2, OSV_STATS | OSV_NO_PREFETCH, 16),
-                                                        ODKL(3, OSV_STATS | OSV_NO_PREFETCH, 16), ODKL(4, OSV_STATS | OSV_NO_PREFETCH, 16)};
-#undef ODK
-#undef ODKL
                 const char *sv = getenv("MGS_OSD_FAKECHAIN"); // timing only: no chained scan, wrong output
                 const char *cv = getenv("MGS_OSD_CHECKED");   // debugging: stores outside the buffers are counted, not made
                 int ki = (sv && atoi(sv) && ov_k == 4) ? 4 : ov_k - 1;
@@ -988,7 +966,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                     q.dbg_lo[1] = (uint64_t) (uintptr_t) d_local_out;
                     q.dbg_hi[1] = q.dbg_lo[1] + (uint64_t) (d_local_out ? local_cap : 0);
                 }
-                hipLaunchKernelGGL(kernels[ki][lm], dim3(grid), dim3(kOvThreads), 0, stream, q);
+                osd_launch(q, ki, lm, grid, stream);
                 if (!may_fall_back) MGS_HIP(h, hipEventRecord(h->ev1, stream));
                 const size_t items = (size_t) max_rounds * ((size_t) P + 1);
                 hipLaunchKernelGGL(k_os_rounds_final, dim3((unsigned) std::min<size_t>(256, (items + 255) / 256)), dim3(256),
@@ -1146,9 +1124,7 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
         for (int b = 0; b < P; b++) bytes += out->send_offset[b] - h->pending_init[b];
         if (recs > 0 && bytes > 0 && h->pending_rounds <= 1 && !h->pending_streams) h->ov_bytes_per_record = (double) bytes / (double) recs;
         if (h->pending_osv) h->ov_shrink = 0; // a one-sweep kernel served the call: the length alone decides again
-        // k_onesweepr: more than one record in 64 did not fit its registers -- wider registers from now on
-        if (h->pending_osv && h->pending_osr && recs > 0 && (uint64_t) h->h_ctrl->head.long_records * 64u > recs)
-            h->osr_nq = 2;
+
     }
     return MGS_OK;
 }

@@ -106,6 +106,7 @@ __device__ __forceinline__ uint32_t od_zero_bytes(uint32_t v)
 
 // Does every worker wave's span of every tile fit its LDS slice?  One thread per
 // (tile, wave).  records_per_wave = 64 * K.
+#ifdef MGS_OSD_UNIT // defined by the one translation unit that launches it
 __global__ void k_osd_check(OvParams q, uint32_t records_per_wave, uint32_t waves)
 {
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,6 +121,7 @@ __global__ void k_osd_check(OvParams q, uint32_t records_per_wave, uint32_t wave
     if (e < s || e - s + shift + OD_FRONT + 20 > (uint64_t) OD_SB)
         __hip_atomic_store(&q.os.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#endif
 
 // The tile starts in round k_cur and holds at least one cut: find every cut in emit
 // order, publish the rounds they begin (see os_find_cuts16; here positions are bytes,

@@ -90,55 +90,43 @@ __device__ __forceinline__ uint32_t osr_zero_flags(uint32_t t)
     return (t - 0x01010101u) & ~t & 0x80808080u;
 }
 
-// lookup3 hashlittle (initval 0) of the first klen bytes (1 <= klen <= 4 * NW) of a record
-// held as NW little-endian words.  CSTR: the key is a C string with its NUL -- `ok` is
-// cleared unless the first zero byte of the key is its last byte.
-template <int NW, bool CSTR>
-__device__ __forceinline__ uint32_t osr_hash_words(const uint32_t (&w)[NW], uint32_t klen, bool &ok)
+// lookup3 hashlittle (initval 0) of the first klen bytes (1 <= klen <= 16) of a record whose
+// first 16 bytes are held as four little-endian words.  ktab: see the kernel.  CSTR: the key
+// is a C string with its NUL -- `ok` is cleared unless the first zero byte of the key is its
+// last byte.
+template <bool CSTR>
+__device__ __forceinline__ uint32_t osr_hash_key16(const uint32_t (&w)[4], uint32_t klen, const uint4 *ktab, bool &ok)
 {
     uint32_t a, b, c;
     a = b = c = 0xdeadbeefu + klen;
-    uint32_t zfull = 0;
-#define OSR_W(i) ((i) < NW ? w[(i) < NW ? (i) : 0] : 0u)
-    auto tail = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t rem) { // 1 <= rem <= 12
-        const uint32_t m0 = osr_byte_mask((int32_t) rem), m1 = osr_byte_mask((int32_t) rem - 4),
-                       m2 = osr_byte_mask((int32_t) rem - 8);
-        const uint32_t x0 = w0 & m0, x1 = w1 & m1, x2 = w2 & m2;
+    if (klen <= 12) {
+        const uint4 m = ktab[klen];
+        const uint32_t x0 = w[0] & m.x, x1 = w[1] & m.y, x2 = w[2] & m.z;
         a += x0;
         b += x1;
         c += x2;
         MGS_FINAL(a, b, c);
         if (CSTR) {
             // bytes beyond the key count as non-zero; byte i of word j is bit 8 * i + j of Z
-            const uint32_t Z = (osr_zero_flags(x0 | ~m0) >> 7) | (osr_zero_flags(x1 | ~m1) >> 6)
-                               | (osr_zero_flags(x2 | ~m2) >> 5);
-            const uint32_t last = rem - 1u;
-            ok = ok && Z == (1u << (8u * (last & 3u) + (last >> 2)));
+            const uint32_t Z = (osr_zero_flags(x0 | ~m.x) >> 7) | (osr_zero_flags(x1 | ~m.y) >> 6)
+                               | (osr_zero_flags(x2 | ~m.z) >> 5);
+            ok = ok && Z == m.w;
         }
-    };
-    if (klen <= 12) {
-        tail(OSR_W(0), OSR_W(1), OSR_W(2), klen);
     }
     else {
-        a += OSR_W(0);
-        b += OSR_W(1);
-        c += OSR_W(2);
+        a += w[0];
+        b += w[1];
+        c += w[2];
         MGS_MIX(a, b, c);
-        if (CSTR) zfull = osr_zero_flags(OSR_W(0)) | osr_zero_flags(OSR_W(1)) | osr_zero_flags(OSR_W(2));
-        if (NW > 6 && klen > 24) {
-            a += OSR_W(3);
-            b += OSR_W(4);
-            c += OSR_W(5);
-            MGS_MIX(a, b, c);
-            if (CSTR) zfull |= osr_zero_flags(OSR_W(3)) | osr_zero_flags(OSR_W(4)) | osr_zero_flags(OSR_W(5));
-            tail(OSR_W(6), OSR_W(7), 0u, klen - 24u);
-        }
-        else {
-            tail(OSR_W(3), OSR_W(4), OSR_W(5), klen - 12u);
+        const uint4 m = ktab[klen - 12u];
+        const uint32_t x0 = w[3] & m.x;
+        a += x0;
+        MGS_FINAL(a, b, c);
+        if (CSTR) {
+            const uint32_t zfull = osr_zero_flags(w[0]) | osr_zero_flags(w[1]) | osr_zero_flags(w[2]);
+            ok = ok && zfull == 0 && (osr_zero_flags(x0 | ~m.x) >> 7) == m.w;
         }
     }
-#undef OSR_W
-    if (CSTR) ok = ok && zfull == 0;
     return c;
 }
 
@@ -146,15 +134,16 @@ __device__ __forceinline__ uint32_t osr_hash_words(const uint32_t (&w)[NW], uint
 // quads per record; LM: 1 = one string key + fixed-width or absent value, 2 = fixed-width
 // key + fixed-width or absent value; A4: every record length, partition base and initial
 // fill is a multiple of four (fixed widths only), so image and partitions are moved as
-// aligned dwords; IMG: bytes of the LDS image.
-template <int THREADS, int K, int NQ, int VAR, int MINW, int LOOK, int LM, bool A4, int IMG>
+// aligned dwords; IMG: bytes of the LDS image; PRE: the first quads of the next tile are
+// requested before the store of the previous tile (16 more registers per 4 records) instead
+// of at the end of the trip.
+template <int THREADS, int K, int NQ, int VAR, int MINW, int LOOK, int LM, bool A4, int IMG, bool PRE>
 __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
 {
     static_assert(LM == 1 || LM == 2, "layout modes 1 and 2");
     static_assert(!A4 || LM == 2, "dword moves need fixed widths");
     const OsParams &p = q.os;
     constexpr int WORKERS = THREADS / 64 - 1, WT = WORKERS * 64, T = WT * K;
-    constexpr int NW = 4 * NQ;
     constexpr uint32_t RB = 16u * NQ; // bytes of a record held in registers
     __shared__ __attribute__((aligned(16))) uint8_t sout[IMG + 32]; // reads run up to 19 bytes past a run
     __shared__ uint32_t wcnt[2 * WORKERS * OS_MAXP];                // bytes per (wave, dest), two tiles
@@ -165,6 +154,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
     __shared__ uint32_t cstart2[2 * (OS_MAXP + 1)];                 // first store unit of dest's run (+ total)
     __shared__ volatile uint32_t misc[4]; // [0] first tile, [1] second tile / tile after next
     __shared__ uint32_t arrive[2];
+    __shared__ __attribute__((aligned(16))) uint4 ktab[16]; // key masks by length (see below)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t P = q.P;  // destinations
@@ -180,6 +170,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
     }
 
     for (int j = tid; j < 2 * WORKERS * OS_MAXP; j += THREADS) wcnt[j] = 0;
+    // key masks: ktab[r] = masks of the first r bytes of three words and the bit that the
+    // NUL of an r-byte string sets in osr_hash_key16's zero-byte word
+    if (tid < 13) {
+        const int r = tid;
+        ktab[r] = make_uint4(osr_byte_mask(r), osr_byte_mask(r - 4), osr_byte_mask(r - 8),
+                             r ? 1u << (8u * ((uint32_t) (r - 1) & 3u) + ((uint32_t) (r - 1) >> 2)) : 0u);
+    }
     if (tid == 0) {
         arrive[0] = 0;
         arrive[1] = 0;
@@ -246,16 +243,22 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
             par ^= 1;
         }
         __syncthreads(); // matches the workers' last barrier
-        if ((VAR & OSV_STATS) && lane == 0) ws.flush(p.ctrl);
         return;
     }
 
     // ------------------------------------------------------------------- workers
+    // (tile numbers come out of LDS: say that they are the same in every lane, so that
+    // everything derived from them is scalar work)
+    tile = (uint32_t) __builtin_amdgcn_readfirstlane((int) tile);
+    next = (uint32_t) __builtin_amdgcn_readfirstlane((int) next);
     const int wt = w * 64 + lane; // worker thread index: owns records wt*K .. wt*K+K-1 of a tile
     uint32_t len[K];              // record k: length (0 = no record)
-    uint32_t rw[K][NW];           // its first RB bytes
-    uint32_t roff[K];             // its byte offset from blob + cur_base (records longer than RB read the rest there)
-    uint64_t cur_base = 0;
+    uint32_t roff[K];             // its first byte, relative to cur_base
+    uint32_t q0[K][4];            // its bytes 0..15
+    uint32_t q1[K][4];            // its bytes 16..31 (NQ = 2), requested at the end of the trip before its own
+    uint64_t cur_base = 0;        // byte of blob the current tile's offsets are relative to
+    uint32_t cur_lim = 0;         // bytes from cur_base to the end of the call's records (clamped)
+    uint32_t cur_end = 0;         // the current tile's last byte + 1, from cur_base
 
     // A zero the compiler cannot see through: an index that is the same in every lane
     // would be fetched with a scalar load, and scalar loads share their completion
@@ -267,88 +270,162 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
     const uint64_t end_abs = q.rec_off ? (uint64_t) q.rec_off[q.first + q.n + vzero]
                                        : (q.first + q.n) * (uint64_t) q.fixed_len;
 
+    // element k (not known at compile time) of a small register array: rare paths only
+    // (each element passes through an empty asm: a plain chain of selects is turned back into
+    // an indexed read of the array, which then lives in scratch memory)
+    auto pick = [](const auto &a, int k) -> uint32_t {
+        uint32_t r = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            uint32_t v = a[j];
+            asm volatile("" : "+v"(v));
+            r = (j == k) ? v : r;
+        }
+        return r;
+    };
+    // up to 16 bytes from global memory, one at a time, as four little-endian words (rare paths)
+    auto bytewise16 = [](const uint8_t *src, uint32_t nbytes, uint32_t (&t)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) t[j] = 0;
+#pragma unroll 1
+        for (uint32_t i = 0; i < nbytes; i++) {
+            const uint32_t v = (uint32_t) src[i] << (8u * (i & 3u));
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((i >> 2) == (uint32_t) j) t[j] |= v;
+        }
+    };
     // Offsets of a tile's records as fetched: K+1 record boundaries of this lane plus the
     // tile's two ends, as 32-bit values relative to `base` (the offset array's own values
-    // with base 0, or multiples of the fixed width with base = the tile's first byte).
+    // with base 0, or multiples of the fixed width with base = the tile's first byte), and
+    // what is known before they arrive.
     struct Offsets {
         uint64_t base;
+        uint32_t lim;  // bytes from base to the end of the call's records (clamped to 32 bits)
         uint32_t rec[K + 1], s, e;
         uint32_t nrec; // records of the tile
     };
     auto fetch_offsets = [&](uint32_t t, Offsets &f) {
-        const uint64_t i0 = (uint64_t) t * T, i1 = min(q.n, i0 + T);
-        f.nrec = (uint32_t) (i1 - i0);
+        const uint64_t i0 = (uint64_t) t * T;
+        const uint64_t left = q.n - i0;
+        f.nrec = left < (uint64_t) T ? (uint32_t) left : (uint32_t) T;
+        const uint32_t first = (uint32_t) (wt * K);
         if (q.rec_off) {
-            const uint32_t *ro = q.rec_off + q.first;
+            const uint32_t *ro = q.rec_off + (q.first + i0); // the same in every lane
             f.base = 0;
-            f.s = ro[i0 + vzero];
-            f.e = ro[i1 + vzero];
+            f.s = ro[vzero];
+            f.e = ro[f.nrec + vzero];
 #pragma unroll
-            for (int k = 0; k <= K; k++) f.rec[k] = ro[min(i1, i0 + (uint64_t) wt * K + k)];
+            for (int k = 0; k <= K; k++) f.rec[k] = ro[min(f.nrec, first + (uint32_t) k)];
         }
         else {
             f.base = (q.first + i0) * (uint64_t) q.fixed_len;
             f.s = 0;
-            f.e = (uint32_t) (i1 - i0) * q.fixed_len;
+            f.e = f.nrec * q.fixed_len;
 #pragma unroll
-            for (int k = 0; k <= K; k++)
-                f.rec[k] = (uint32_t) (min(i1, i0 + (uint64_t) wt * K + k) - i0) * q.fixed_len;
+            for (int k = 0; k <= K; k++) f.rec[k] = min(f.nrec, first + (uint32_t) k) * q.fixed_len;
         }
+        const uint64_t room = end_abs > f.base ? end_abs - f.base : 0ull;
+        f.lim = room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) room;
     };
-    // May record k of the tile be fetched with whole 16-byte loads?  It must exist, lie inside
-    // the tile's span, and its RB bytes must end inside the call's records.
-    auto quad_ok = [&](const Offsets &f, int k) -> bool {
-        return f.rec[k + 1] > f.rec[k] && f.rec[k] >= f.s && f.rec[k + 1] <= f.e && f.e >= f.s
-               && f.base + f.rec[k] + RB <= end_abs;
-    };
-    // Issue the loads of a tile's records (nothing is computed from the loaded values here).
-    auto issue_loads = [&](const Offsets &f, uint32_t (&r)[K][NW]) {
+    // May bytes [at, at + 16) from the tile's base be fetched with one 16-byte load?  They must end
+    // inside the call's records.
+    auto quad_ok = [](uint32_t at, uint32_t lim) -> bool { return lim >= 16u && at <= lim - 16u; };
+    // Issue the loads of the first 16 bytes of a tile's records (nothing is computed from the
+    // loaded values here).
+    auto issue_q0 = [&](const Offsets &f, uint32_t (&r)[K][4]) {
         const uint8_t *tb = q.blob + f.base;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const bool okq = quad_ok(f, k);
-#pragma unroll
-            for (int j = 0; j < NQ; j++) {
-                OvU128 v = {0, 0, 0, 0};
-                if (okq) v = *reinterpret_cast<const OvU128 *>(tb + f.rec[k] + 16u * j);
-                r[k][4 * j + 0] = v.x;
-                r[k][4 * j + 1] = v.y;
-                r[k][4 * j + 2] = v.z;
-                r[k][4 * j + 3] = v.w;
-            }
+            // Every lane loads, from an address clamped into the call's records (or, when those
+            // are shorter than one load, from the control block): a load under a condition is
+            // followed by a select between its result and zero, and that select waits for the
+            // load -- one round trip after the other.  What a clamped load fetches is never
+            // looked at (the record's length is zero, or its bytes are fetched one by one in
+            // settle).  The clamp keeps the lanes' addresses apart: one address for all of them
+            // would be one cache line for the whole GPU.
+            const uint8_t *src = f.lim >= 16u ? tb + min(f.rec[k], f.lim - 16u) : reinterpret_cast<const uint8_t *>(p.ctrl);
+            const OvU128 v = *reinterpret_cast<const OvU128 *>(src);
+            r[k][0] = v.x;
+            r[k][1] = v.y;
+            r[k][2] = v.z;
+            r[k][3] = v.w;
         }
     };
     // Lengths and checks of a tile's records; the few records next to the end of the call
-    // (quad_ok said no) are fetched byte by byte.
-    auto settle = [&](const Offsets &f, uint32_t (&r)[K][NW]) {
+    // (no whole 16-byte load) are fetched byte by byte.  A record is what its offsets promise
+    // when it is not empty and not longer than a record may be (offsets that are not monotonic
+    // wrap to a huge length) and the lane's first and last boundary lie inside the tile's span;
+    // boundaries past the end of the call all equal the tile's end (length zero: no record).
+    auto settle = [&](const Offsets &f) {
         const bool fits = f.e >= f.s && f.e - f.s <= (uint32_t) IMG;
         cur_base = f.base;
+        cur_lim = f.lim;
+        cur_end = f.e;
         if (!fits) // the tile's bytes do not fit the image: the host redoes the call with other kernels
             __hip_atomic_store(&p.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t first = (uint32_t) (wt * K);
+        const uint32_t mine = f.nrec > first ? min(f.nrec - first, (uint32_t) K) : 0u; // records of this lane
+        const bool inside = f.rec[0] >= f.s && f.rec[K] <= f.e;
+        bool bad = mine != 0 && !inside;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const uint32_t l = f.rec[k + 1] - f.rec[k]; // wraps to a huge value when not monotonic
-            len[k] = fits ? l : 0u;
+            const uint32_t l = f.rec[k + 1] - f.rec[k];
+            const bool good = l - 1u < GEN_MAX_RECORD;
             roff[k] = f.rec[k];
-            if (l == 0) { // past the end of the call -- or an empty record, which no layout produces
-                if ((uint32_t) (wt * K + k) < f.nrec) raise_error(p.ctrl, MGS_ERR_MALFORMED);
-                continue;
-            }
-            if (l > GEN_MAX_RECORD || f.rec[k] < f.s || f.rec[k + 1] > f.e || f.rec[k + 1] < f.rec[k]) {
-                raise_error(p.ctrl, MGS_ERR_MALFORMED);
-                len[k] = 0;
-                continue;
-            }
-            if (fits && !quad_ok(f, k)) {
-                const uint8_t *src = q.blob + f.base + f.rec[k];
-                const uint32_t nbytes = l < RB ? l : RB;
+            len[k] = (fits && inside && good) ? l : 0u;
+            bad = bad || (!good && (uint32_t) k < mine);
+        }
+        if (bad) raise_error(p.ctrl, MGS_ERR_MALFORMED);
+        if (__any(f.e + 16u > f.lim)) { // the tile ends next to the end of the call: its last record or two
+            uint32_t bytewise = 0;
 #pragma unroll
-                for (int j = 0; j < NW; j++) r[k][j] = 0;
-                for (uint32_t i = 0; i < nbytes; i++) {
-                    const uint32_t v = (uint32_t) src[i] << (8u * (i & 3u));
+            for (int k = 0; k < K; k++)
+                if (len[k] != 0 && !quad_ok(f.rec[k], f.lim)) bytewise |= 1u << k;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                if (!((bytewise >> k) & 1u)) continue;
+                const uint32_t l = pick(len, k);
+                uint32_t t[4];
+                bytewise16(q.blob + f.base + pick(roff, k), l < 16u ? l : 16u, t);
 #pragma unroll
-                    for (int j = 0; j < NW; j++)
-                        if ((i >> 2) == (uint32_t) j) r[k][j] |= v;
+                for (int kk = 0; kk < K; kk++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (kk == k) q0[kk][j] = t[j];
+                }
+            }
+        }
+    };
+    // Bytes 16..31 of the records that have them (after settle: the lengths are known).
+    auto load_q1 = [&](uint32_t (&t)[K][4]) {
+        const uint8_t *tb = q.blob + cur_base;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint8_t *src = cur_lim >= 16u ? tb + min(roff[k] + 16u, cur_lim - 16u) // (clamped: see issue_q0)
+                                                : reinterpret_cast<const uint8_t *>(p.ctrl);
+            const OvU128 v = *reinterpret_cast<const OvU128 *>(src);
+            t[k][0] = v.x;
+            t[k][1] = v.y;
+            t[k][2] = v.z;
+            t[k][3] = v.w;
+        }
+        if (__any(cur_end + 16u > cur_lim)) { // the tile ends next to the end of the call
+            uint32_t bytewise = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (len[k] > 16u && !quad_ok(roff[k] + 16u, cur_lim)) bytewise |= 1u << k;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                if (!((bytewise >> k) & 1u)) continue;
+                const uint32_t l = pick(len, k) - 16u;
+                uint32_t b16[4];
+                bytewise16(tb + pick(roff, k) + 16u, l < 16u ? l : 16u, b16);
+#pragma unroll
+                for (int kk = 0; kk < K; kk++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (kk == k) t[kk][j] = b16[j];
                 }
             }
         }
@@ -363,9 +440,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         for (uint32_t u = (uint32_t) w; u < utotal; u += WORKERS) {
             const uint32_t b = (uint32_t) __popcll(__ballot(my_ustart <= u)) - 1u; // last dest starting at or before u
             const uint32_t u0 = (uint32_t) __builtin_amdgcn_readlane((int) my_ustart, (int) b);
-            const unsigned long long G = gaddr2[pr * OS_MAXP + b];
-            const uint32_t nb = nbytes2[pr * OS_MAXP + b];
-            const uint32_t ds = dstart2[pr * OS_MAXP + b]; // image byte of global byte G
+            // (the unit's table entries are the same in every lane: scalar work from here)
+            const unsigned long long Gv = gaddr2[pr * OS_MAXP + b];
+            const unsigned long long G =
+                ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (Gv >> 32)) << 32)
+                | (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) Gv);
+            const uint32_t nb = (uint32_t) __builtin_amdgcn_readfirstlane((int) nbytes2[pr * OS_MAXP + b]);
+            const uint32_t ds = (uint32_t) __builtin_amdgcn_readfirstlane((int) dstart2[pr * OS_MAXP + b]); // image byte of global byte G
             const uint32_t a = (uint32_t) G & 15u;         // the run starts `a` bytes into its first chunk
             const uint32_t off = ((u - u0) * 64u + (uint32_t) lane) << 4; // this lane's chunk, from the aligned start
             // whole chunks only; the partial chunks at the two ends of the runs follow below
@@ -449,8 +530,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         if (n & 1u) *o = (uint8_t) a0;
     };
 
+
     Offsets fn; // offsets of the tile after the current one: fetched one whole trip before its bytes
     fn.base = 0;
+    fn.lim = 0;
     fn.s = fn.e = 0;
     fn.nrec = 0;
 #pragma unroll
@@ -459,60 +542,114 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
     for (int k = 0; k < K; k++) {
         len[k] = 0;
         roff[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) q0[k][j] = q1[k][j] = 0;
     }
     if (tile < p.ntiles) {
         Offsets f0;
         fetch_offsets(tile, f0);
         if (next < p.ntiles) fetch_offsets(next, fn);
-        issue_loads(f0, rw);
-        settle(f0, rw);
+        issue_q0(f0, q0);
+        settle(f0);
+        if (NQ > 1) load_q1(q1);
     }
     bool have_prev = false;
+    // diagnostic build: cycles of worker wave 0 per phase of the trip
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    if (VAR & OSV_STATS) tprev = __builtin_readcyclecounter();
+#define OSR_PHASE(i)                                                     \
+    if (VAR & OSV_STATS) {                                               \
+        const unsigned long long tnow = __builtin_readcyclecounter();    \
+        ph[i] += tnow - tprev;                                           \
+        tprev = tnow;                                                    \
+    }
     const uint32_t vlen = (q.lay.val_kind == MGS_VAL_FIXED) ? (uint32_t) q.lay.val_bytes : 0u;
+    const uint32_t fixed_klen = (uint32_t) q.lay.key_bytes; // LM == 2
 
     while (tile < p.ntiles) {
         uint32_t *wc = wcnt + par * (WORKERS * OS_MAXP);
         // ---- hash: destination of each of this lane's records
         uint32_t d[K];
+        uint32_t longkey = 0; // string keys of more than 12 bytes: hashed below, one at a time
+        bool bad = false;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            d[k] = 0xFFu;
-            if (len[k] == 0) continue;
-            uint32_t hk = 0;
-            uint32_t klen;
-            bool ok;
             if (LM == 1) {
-                klen = len[k] - vlen;
-                ok = len[k] > vlen;
+                // straight-line code: a record that does not exist (length 0) or whose key is not
+                // 1..12 bytes long computes on zero masks and is sorted out by the flags
+                const uint32_t klen = len[k] - vlen;
+                const bool have = len[k] != 0, nokey = have && len[k] <= vlen;
+                const bool shortk = klen - 1u < 12u && len[k] > vlen;
+                const uint4 m = ktab[shortk ? klen : 0u];
+                const uint32_t x0 = q0[k][0] & m.x, x1 = q0[k][1] & m.y, x2 = q0[k][2] & m.z;
+                uint32_t a, b, c;
+                a = b = c = 0xdeadbeefu + klen;
+                a += x0;
+                b += x1;
+                c += x2;
+                MGS_FINAL(a, b, c);
+                // the key's NUL rule: bytes beyond the key count as non-zero; byte i of word j is bit 8 * i + j of Z
+                const uint32_t Z = (osr_zero_flags(x0 | ~m.x) >> 7) | (osr_zero_flags(x1 | ~m.y) >> 6)
+                                   | (osr_zero_flags(x2 | ~m.z) >> 5);
+                const bool valid = shortk && Z == m.w;
+                const bool lk = have && !nokey && !shortk;
+                bad = bad || nokey || (have && shortk && !valid);
+                d[k] = valid ? (p.fm.pow2 ? fastmod_pow2(c, p.fm) : fastmod_magic(c, p.fm)) : 0xFFu;
+                len[k] = (valid || lk) ? len[k] : 0u;
+                if (lk) longkey |= 1u << k;
             }
             else {
-                klen = (uint32_t) q.lay.key_bytes;
-                ok = klen <= len[k];
+                d[k] = 0xFFu;
+                bool ok = fixed_klen <= len[k] && fixed_klen <= 16u; // (the same for every record)
+                uint32_t hk = 0;
+                if (ok) hk = osr_hash_key16<false>(q0[k], fixed_klen, ktab, ok);
+                if (len[k] != 0 && !ok) bad = true;
+                if (len[k] != 0 && ok) d[k] = p.fm.pow2 ? fastmod_pow2(hk, p.fm) : fastmod_magic(hk, p.fm);
+                else len[k] = 0;
             }
-            if (ok && klen <= RB) {
-                hk = osr_hash_words<NW, LM == 1>(rw[k], klen, ok);
-            }
-            else if (ok) {
-                // a key longer than the registers hold: from global memory, byte by byte
-                const uint8_t *r = q.blob + cur_base + roff[k];
-                if (LM == 1) {
-                    ok = r[klen - 1] == 0;
-                    for (uint32_t j = 0; j + 1 < klen; j++) ok = ok && r[j] != 0;
-                }
-                hk = hashlittle_bytes(r, klen);
-            }
-            if (!ok) {
-                raise_error(p.ctrl, MGS_ERR_MALFORMED);
-                len[k] = 0;
-                continue;
-            }
-            d[k] = p.fm.pow2 ? fastmod_pow2(hk, p.fm) : fastmod_magic(hk, p.fm);
         }
+        if (LM == 1 && __any(longkey != 0)) {
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                if (!((longkey >> k) & 1u)) continue;
+                const uint32_t klen = pick(len, k) - vlen;
+                bool ok = true;
+                uint32_t hk;
+                if (klen <= 16u) { // still inside the first quad
+                    uint32_t w4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t col[K];
+#pragma unroll
+                        for (int kk = 0; kk < K; kk++) col[kk] = q0[kk][j];
+                        w4[j] = pick(col, k);
+                    }
+                    hk = osr_hash_key16<true>(w4, klen, ktab, ok);
+                }
+                else { // from global memory, byte by byte
+                    const uint8_t *r = q.blob + cur_base + pick(roff, k);
+                    ok = r[klen - 1] == 0;
+#pragma unroll 1
+                    for (uint32_t j = 0; j + 1 < klen; j++) ok = ok && r[j] != 0;
+                    hk = hashlittle_bytes(r, klen);
+                }
+                const uint32_t dk = p.fm.pow2 ? fastmod_pow2(hk, p.fm) : fastmod_magic(hk, p.fm);
+                bad = bad || !ok;
+#pragma unroll
+                for (int kk = 0; kk < K; kk++) {
+                    if (kk != k) continue;
+                    d[kk] = ok ? dk : 0xFFu;
+                    if (!ok) len[kk] = 0;
+                }
+            }
+        }
+        if (bad) raise_error(p.ctrl, MGS_ERR_MALFORMED);
         if (p.dest_out) {
 #pragma unroll
             for (int k = 0; k < K; k++)
                 if (len[k]) p.dest_out[(uint64_t) tile * T + (uint64_t) wt * K + k] = (uint8_t) d[k];
         }
+        OSR_PHASE(0)
         // ---- rank: byte position of each record inside the wave's share of its destination.
         // Two destinations share one scan: 16-bit fields (a wave's bytes fit: the tile's
         // bytes fit the image).
@@ -561,7 +698,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
                 os_publish_agg16(p, tile, lane, tot_all);
             }
         }
+        OSR_PHASE(1)
         __syncthreads(); // A: counts(tile) complete; tables of the previous tile are ready
+        OSR_PHASE(2)
         // the phases that issue memory operations go before the other waves' hashing
         __builtin_amdgcn_s_setprio(1);
 
@@ -576,13 +715,20 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         const uint32_t first_byte = wave_incl_scan_u32(tot, lane) - tot;
         wslot[w * OS_MAXP + lane] = first_byte + below;
         if (w == 0) dstart2[par * OS_MAXP + lane] = first_byte;
+        // the first quads of the next tile's records (its offsets arrived during the last
+        // trip): in flight during the store and the reorder
+        uint32_t nx[K][4];
+        if (PRE) issue_q0(fn, nx); // (offsets of a tile that does not exist are all zero: nothing is loaded)
         if (have_prev) store_image(par ^ 1);
+        OSR_PHASE(3)
         __syncthreads(); // B: the image is free
-        const uint32_t next2 = misc[1];
+        OSR_PHASE(4)
+        const uint32_t next2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) misc[1]);
 
         // offsets of the tile after the next: in flight during the reorder
         Offsets fn2;
         fn2.base = 0;
+        fn2.lim = 0;
         fn2.s = fn2.e = 0;
         fn2.nrec = 0;
 #pragma unroll
@@ -593,32 +739,39 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
             uint32_t dst[K];
 #pragma unroll
             for (int k = 0; k < K; k++) dst[k] = wslot[w * OS_MAXP + (len[k] ? d[k] : 0u)] + pw[k];
+            bool more = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) more |= len[k] > 16u;
             if (A4) {
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     if (len[k] == 0) continue;
                     uint32_t *o = reinterpret_cast<uint32_t *>(sout + dst[k]);
 #pragma unroll
-                    for (int j = 0; j < NW; j++)
-                        if ((uint32_t) (4 * j) < len[k]) o[j] = rw[k][j];
+                    for (int j = 0; j < 4; j++)
+                        if ((uint32_t) (4 * j) < len[k]) o[j] = q0[k][j];
+                }
+                if (NQ > 1 && __any(more)) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        uint32_t *o = reinterpret_cast<uint32_t *>(sout + dst[k]);
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if ((uint32_t) (16 + 4 * j) < len[k]) o[4 + j] = q1[k][j];
+                    }
                 }
             }
             else {
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     if (len[k] == 0) continue;
-                    put(sout + dst[k], rw[k][0], rw[k][1], rw[k][2], rw[k][3], len[k]);
+                    put(sout + dst[k], q0[k][0], q0[k][1], q0[k][2], q0[k][3], len[k]);
                 }
-                if (NQ > 1) {
-                    bool more = false;
+                if (NQ > 1 && __any(more)) {
 #pragma unroll
-                    for (int k = 0; k < K; k++) more |= len[k] > 16;
-                    if (__any(more)) {
-#pragma unroll
-                        for (int k = 0; k < K; k++) {
-                            if (len[k] <= 16) continue;
-                            put(sout + dst[k] + 16, rw[k][NW - 4], rw[k][NW - 3], rw[k][NW - 2], rw[k][NW - 1], len[k] - 16);
-                        }
+                    for (int k = 0; k < K; k++) {
+                        if (len[k] <= 16) continue;
+                        put(sout + dst[k] + 16, q1[k][0], q1[k][1], q1[k][2], q1[k][3], len[k] - 16);
                     }
                 }
             }
@@ -628,27 +781,40 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
             for (int k = 0; k < K; k++) longer |= len[k] > RB;
             if (__any(longer)) {
                 uint32_t nlong = 0;
-                for (int k = 0; k < K; k++) { // not unrolled: rare
-                    if (len[k] <= RB) continue;
+#pragma unroll 1
+                for (int k = 0; k < K; k++) {
+                    const uint32_t l = pick(len, k);
+                    if (l <= RB) continue;
                     nlong++;
-                    const uint8_t *src = q.blob + cur_base + roff[k];
-                    uint8_t *o = sout + dst[k];
-                    for (uint32_t j = RB; j < len[k]; j++) o[j] = src[j];
+                    const uint8_t *src = q.blob + cur_base + pick(roff, k);
+                    uint8_t *o = sout + pick(dst, k);
+#pragma unroll 1
+                    for (uint32_t j = RB; j < l; j++) o[j] = src[j];
                 }
                 if (nlong) atomicAdd(&p.ctrl->head.long_records, nlong);
             }
         }
-        // the registers are free again: the records of the next tile (its offsets arrived
-        // during the last trip); the other waves' work covers the round trip
-        if (next < p.ntiles) {
-            issue_loads(fn, rw);
-            settle(fn, rw);
+        // the next tile's records become the current ones
+        OSR_PHASE(5)
+        if (PRE) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) q0[k][j] = nx[k][j];
+            }
         }
         else {
+            issue_q0(fn, q0); // the registers are free again; the other waves' work covers the round trip
+        }
+        settle(fn); // (a tile that does not exist: every length becomes zero)
+        if (NQ > 1) {
+            bool more2 = false;
 #pragma unroll
-            for (int k = 0; k < K; k++) len[k] = 0;
+            for (int k = 0; k < K; k++) more2 |= len[k] > 16u;
+            if (__any(more2)) load_q1(q1);
         }
         fn = fn2;
+        OSR_PHASE(6)
         __builtin_amdgcn_s_setprio(0);
         have_prev = true;
         tile = next;
@@ -657,6 +823,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
     }
     __syncthreads(); // tables of the last tile are ready
     if (have_prev) store_image(par ^ 1);
+    if ((VAR & OSV_STATS) && wt == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(&p.ctrl->head.stats[i], ph[i]);
+    }
+#undef OSR_PHASE
 }
 
 } // namespace mgs

@@ -9,34 +9,45 @@ namespace {
 typedef void (*OsrKernel)(OvParams);
 struct OsrEntry {
     int k, nq, lm;
-    bool a4, stats;
+    bool a4, pre;
+    int var; // OSV_* bits of the instantiation (0: production)
     OsrKernel fn;
 };
-#define OSR(K, NQ, LM, A4, V) \
-    {K, NQ, LM, A4, (V) != 0, k_onesweepr<OSR_THREADS, K, NQ, V, 4, 8, LM, A4, (NQ == 1 ? OSR_IMG1 : OSR_IMG2)>}
+#define OSR(K, NQ, LM, A4, PRE, V) \
+    {K, NQ, LM, A4, PRE, V, k_onesweepr<OSR_THREADS, K, NQ, V, 4, 8, LM, A4, (NQ == 1 ? OSR_IMG1 : OSR_IMG2), PRE>}
 const OsrEntry kOsr[] = {
     // one string key + fixed-width or absent value
-    OSR(4, 1, 1, false, 0), OSR(4, 2, 1, false, 0), OSR(2, 2, 1, false, 0), OSR(1, 2, 1, false, 0),
+    OSR(4, 2, 1, false, false, 0), OSR(3, 2, 1, false, true, 0), OSR(3, 2, 1, false, false, 0), OSR(2, 2, 1, false, true, 0),
+    OSR(1, 2, 1, false, true, 0),
     // fixed widths up to 16 / 32 bytes; multiples of four bytes move as dwords
-    OSR(4, 1, 2, false, 0), OSR(4, 2, 2, false, 0), OSR(4, 1, 2, true, 0), OSR(4, 2, 2, true, 0),
+    OSR(4, 1, 2, false, true, 0), OSR(4, 2, 2, false, false, 0), OSR(3, 2, 2, false, true, 0),
+    OSR(4, 1, 2, true, true, 0), OSR(4, 2, 2, true, false, 0), OSR(3, 2, 2, true, true, 0),
+    // diagnostic builds: cycles per phase
+    OSR(4, 2, 1, false, false, OSV_STATS), OSR(3, 2, 1, false, true, OSV_STATS), OSR(4, 2, 2, true, false, OSV_STATS),
+    OSR(4, 1, 2, true, true, OSV_STATS),
+    // timing only (wrong output): no chained scan, positions are made up -- prices the chain
+    OSR(4, 2, 1, false, false, OSV_FAKE_CHAIN), OSR(3, 2, 1, false, true, OSV_FAKE_CHAIN), OSR(4, 2, 2, true, false, OSV_FAKE_CHAIN),
 };
 #undef OSR
-const OsrEntry *find(int k, int nq, int lm, bool a4, bool stats)
+const OsrEntry *find(int k, int nq, int lm, bool a4, int pre, int var)
 {
     for (const OsrEntry &e : kOsr)
-        if (e.k == k && e.nq == nq && e.lm == lm && e.a4 == a4 && e.stats == stats) return &e;
+        if (e.k == k && e.nq == nq && e.lm == lm && e.a4 == a4 && (pre < 0 || e.pre == (pre != 0)) && e.var == var)
+            return &e;
     return nullptr;
 }
 } // namespace
 
 int osr_image_bytes(int nq) { return nq == 1 ? OSR_IMG1 : OSR_IMG2; }
 
-bool osr_has(int k, int nq, int lm, bool a4) { return find(k, nq, lm, a4, false) != nullptr; }
+bool osr_has(int k, int nq, int lm, bool a4) { return find(k, nq, lm, a4, -1, 0) != nullptr; }
 
-bool osr_launch(const OvParams &q, int k, int nq, int lm, bool a4, bool stats, uint32_t grid, hipStream_t stream)
+bool osr_launch(const OvParams &q, int k, int nq, int lm, bool a4, int pre, int var, uint32_t grid, hipStream_t stream)
 {
-    const OsrEntry *e = find(k, nq, lm, a4, stats);
-    if (!e) e = find(k, nq, lm, a4, false);
+    const OsrEntry *e = find(k, nq, lm, a4, pre, var);
+    if (!e) e = find(k, nq, lm, a4, -1, var);
+    if (!e) e = find(k, nq, lm, a4, pre, 0);
+    if (!e) e = find(k, nq, lm, a4, -1, 0);
     if (!e) return false;
     hipLaunchKernelGGL(e->fn, dim3(grid), dim3(OSR_THREADS), 0, stream, q);
     return true;

@@ -62,14 +62,20 @@ def main():
         med = ms[len(ms) // 2]
         alg = 2 * total + (4 * (n + 1) if offs is not None else 0)
         kms = pk.last_kernel_ms()
-        if os.environ.get("MGS_OSV_STATS") and pk.last_algo() == "onesweepv":
+        if os.environ.get("MGS_OSR_STATS") and pk.last_kernel() == "k_onesweepr":
+            st = pk.debug_stats()
+            tot = max(sum(st), 1)
+            names = ["hash", "rank", "wait A", "store", "wait B", "reorder", "next loads + settle", "-"]
+            print("# k_onesweepr worker wave 0, share of cycles: " +
+                  ", ".join(f"{nm} {v / tot:.1%}" for nm, v in zip(names, st)), flush=True)
+        elif os.environ.get("MGS_OSV_STATS") and pk.last_algo() == "onesweepv":
             st = pk.debug_stats()
             tot = max(sum(st), 1)
             names = ["hash", "rank", "wait A", "store", "wait B", "reorder", "wait C + park", "wait D"]
             print("# worker wave 0, share of cycles: " +
                   ", ".join(f"{nm} {v / tot:.1%}" for nm, v in zip(names, st)), flush=True)
         line = {"workload": name, "kernel_ms": kms, "records": n, "bytes": total, "algo": pk.last_algo(),
-                "ms": med, "records_per_s": n / med * 1e3, "GBps_algorithmic": alg / med / 1e6,
+                "kernel": pk.last_kernel(), "ms": med, "records_per_s": n / med * 1e3, "GBps_algorithmic": alg / med / 1e6,
                 "frac_of_8TBps": alg / med / 1e6 / 8000}
         print(json.dumps(line), flush=True)
         out.append(line)
