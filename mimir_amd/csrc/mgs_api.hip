@@ -904,7 +904,9 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
                     static const char *sv = getenv("MGS_OSR_STATS");
                     static const char *pv = getenv("MGS_OSR_PRE"); // experiments: pin early / late requests
                     static const char *fv = getenv("MGS_OSR_FAKECHAIN"); // timing only, wrong output
-                    const int var = (sv && atoi(sv)) ? OSV_STATS : ((fv && atoi(fv)) ? OSV_FAKE_CHAIN : 0);
+                    // MGS_OSR_STATS: 1 = worker wave 0 reports, 2 = the last worker wave
+                    const int var = ((sv && atoi(sv)) ? (atoi(sv) == 2 ? OSV_STATS | OSV_NO_PREFETCH : OSV_STATS) : 0)
+                                    | ((fv && atoi(fv)) ? OSV_FAKE_CHAIN : 0);
                     if (!osr_launch(q, osr_k, osr_nq, lm, osr_a4, pv ? atoi(pv) : -1, var, grid, stream)) {
                         h->err = "mgs_pack_device: no k_onesweepr instantiation for this call";
                         return MGS_ERR_ARG;

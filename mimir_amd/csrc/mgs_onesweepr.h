@@ -187,6 +187,52 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
     uint32_t tile = misc[0], next = misc[1];
     int par = 0;
 
+    // The partial chunks at the two ends of the runs of a tile's image (at most two per
+    // destination): one wave, lane = (destination, end), so that the divergent byte work runs
+    // once per tile.  In the loop the scan wave does it, in the time it would otherwise spend
+    // waiting at barrier B; after the loop, the last worker wave.
+    auto store_partials = [&](int pr) {
+        for (uint32_t it = (uint32_t) lane; it < 2u * P; it += 64u) {
+            const uint32_t b = it >> 1;
+            const unsigned long long G = gaddr2[pr * OS_MAXP + b];
+            const uint32_t nb = nbytes2[pr * OS_MAXP + b];
+            if (nb == 0) continue;
+            const uint32_t nch = (uint32_t) (((G & 15ull) + nb + 15ull) >> 4);
+            if ((it & 1u) && nch == 1) continue; // the only chunk is taken as the first
+            const unsigned long long g0 = (G & ~15ull) + ((it & 1u) ? (unsigned long long) (nch - 1u) << 4 : 0ull);
+            if (g0 >= G && g0 + 16 <= G + nb) continue; // a whole chunk: stored above
+            // naturally aligned pieces, growing from the first byte, then shrinking towards the last
+            const uint8_t *src0 = sout + dstart2[pr * OS_MAXP + b];
+            unsigned long long ga = g0 > G ? g0 : G;
+            const unsigned long long gb = g0 + 16 < G + nb ? g0 + 16 : G + nb;
+            if ((ga & 1) && ga + 1 <= gb) {
+                *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
+                ga += 1;
+            }
+            if ((ga & 2) && ga + 2 <= gb) {
+                *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
+                ga += 2;
+            }
+            if ((ga & 4) && ga + 4 <= gb) {
+                *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
+                ga += 4;
+            }
+            if (ga + 8 <= gb) {
+                *reinterpret_cast<unsigned long long *>(ga) = reinterpret_cast<const OvU64 *>(src0 + (ga - G))->v;
+                ga += 8;
+            }
+            if (ga + 4 <= gb) {
+                *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
+                ga += 4;
+            }
+            if (ga + 2 <= gb) {
+                *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
+                ga += 2;
+            }
+            if (ga + 1 <= gb) *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
+        }
+        };
+
     // ------------------------------------------------------------------ scan wave
     if (w == WORKERS) {
         // every later tile waits for this wave's prefix: it goes first at the issue arbiter
@@ -195,6 +241,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         const bool live = (uint32_t) lane < PC, is_dest = (uint32_t) lane < P;
         const unsigned long long my_base = is_dest ? p.ctrl->head.part_base[lane] : 0ull;
         const unsigned long long my_cap = is_dest ? (unsigned long long) p.ctrl->head.part_cap[lane] : 0ull;
+        bool scan_have_prev = false;
         while (tile < p.ntiles) {
             const uint32_t *wc = wcnt + par * (WORKERS * OS_MAXP);
             __syncthreads(); // A: counts(tile) complete
@@ -211,6 +258,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
             if (lane == 0) misc[1] = atomicAdd(&p.ctrl->head.ticket, 1u);
             for (int j = lane; j < WORKERS * OS_MAXP; j += 64) wcnt[(par ^ 1) * (WORKERS * OS_MAXP) + j] = 0;
             if (lane == 0) arrive[par ^ 1] = 0;
+            if (scan_have_prev) store_partials(par ^ 1); // of the image the workers are storing now
+            scan_have_prev = true;
             __syncthreads(); // B
             const uint32_t next2 = misc[1];
             if ((VAR & OSV_FAKE_CHAIN) && tile != 0) { // timing only: made-up positions, no scan
@@ -433,77 +482,61 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
     // Stream out the image of a tile (parity pr).  A wave takes one unit at a time: 64
     // consecutive 16-byte chunks of one destination's run, so everything but the chunk
     // index is the same in all its lanes.
-    auto store_image = [&](int pr) {
+    auto store_image = [&](int pr, bool with_partials) {
         const uint32_t *ustart = cstart2 + pr * (OS_MAXP + 1);
         const uint32_t utotal = ustart[OS_MAXP];
-        const uint32_t my_ustart = ustart[lane]; // lane = destination; non-decreasing, total from P on
-        for (uint32_t u = (uint32_t) w; u < utotal; u += WORKERS) {
+        // lane = destination: the tables of its run, read once; a unit's entries then come out of
+        // these registers by lane number, with no trip to LDS in the loop
+        const uint32_t my_ustart = ustart[lane]; // non-decreasing, total from P on
+        const unsigned long long my_G = gaddr2[pr * OS_MAXP + lane];
+        const uint32_t my_nb = nbytes2[pr * OS_MAXP + lane], my_ds = dstart2[pr * OS_MAXP + lane];
+        // one unit: 64 consecutive 16-byte chunks of one destination's run, a chunk per lane
+        struct Unit {
+            unsigned long long gbase; // global address of the unit's first chunk (16-byte aligned)
+            uint32_t src;             // image byte that goes to gbase
+            bool on;                  // this lane's chunk is a whole chunk of the run
+        };
+        auto unit = [&](uint32_t u) -> Unit {
             const uint32_t b = (uint32_t) __popcll(__ballot(my_ustart <= u)) - 1u; // last dest starting at or before u
             const uint32_t u0 = (uint32_t) __builtin_amdgcn_readlane((int) my_ustart, (int) b);
-            // (the unit's table entries are the same in every lane: scalar work from here)
-            const unsigned long long Gv = gaddr2[pr * OS_MAXP + b];
             const unsigned long long G =
-                ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (Gv >> 32)) << 32)
-                | (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) Gv);
-            const uint32_t nb = (uint32_t) __builtin_amdgcn_readfirstlane((int) nbytes2[pr * OS_MAXP + b]);
-            const uint32_t ds = (uint32_t) __builtin_amdgcn_readfirstlane((int) dstart2[pr * OS_MAXP + b]); // image byte of global byte G
-            const uint32_t a = (uint32_t) G & 15u;         // the run starts `a` bytes into its first chunk
-            const uint32_t off = ((u - u0) * 64u + (uint32_t) lane) << 4; // this lane's chunk, from the aligned start
-            // whole chunks only; the partial chunks at the two ends of the runs follow below
-            if (off >= a && off + 16u <= a + nb) {
-                uint4 val;
-                if (A4) {
-                    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(sout + (ds + off - a));
-                    val = make_uint4(s4[0], s4[1], s4[2], s4[3]);
-                }
-                else {
-                    val = ov_lds_read16(sout, ds + off - a);
-                }
-                *reinterpret_cast<uint4 *>((G - a) + off) = val;
+                ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (my_G >> 32), (int) b) << 32)
+                | (unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) my_G, (int) b);
+            const uint32_t nb = (uint32_t) __builtin_amdgcn_readlane((int) my_nb, (int) b);
+            const uint32_t ds = (uint32_t) __builtin_amdgcn_readlane((int) my_ds, (int) b); // image byte of global byte G
+            const uint32_t a = (uint32_t) G & 15u; // the run starts `a` bytes into its first chunk
+            const uint32_t off0 = (u - u0) << 10;  // the unit's first chunk, from the run's aligned start
+            const uint32_t off = off0 + ((uint32_t) lane << 4);
+            Unit r;
+            r.gbase = (G - a) + off0;
+            r.src = ds + off0 - a; // (wraps below zero only where `on` is false)
+            r.on = off >= a && off + 16u <= a + nb; // whole chunks only; the partial ones follow below
+            return r;
+        };
+        auto read_chunk = [&](const Unit &t) -> uint4 {
+            const uint32_t at = t.on ? t.src + ((uint32_t) lane << 4) : 0u;
+            if (A4) {
+                const uint32_t *s4 = reinterpret_cast<const uint32_t *>(sout + at);
+                return make_uint4(s4[0], s4[1], s4[2], s4[3]);
             }
+            return ov_lds_read16(sout, at);
+        };
+        auto write_chunk = [&](const Unit &t, const uint4 &val) {
+            if (t.on) *reinterpret_cast<uint4 *>(t.gbase + ((unsigned long long) lane << 4)) = val;
+        };
+        // two units per trip: both chunks are read before either is stored
+        uint32_t u = (uint32_t) w;
+        for (; u + WORKERS < utotal; u += 2 * WORKERS) {
+            const Unit t0 = unit(u), t1 = unit(u + WORKERS);
+            const uint4 v0 = read_chunk(t0), v1 = read_chunk(t1);
+            write_chunk(t0, v0);
+            write_chunk(t1, v1);
         }
-        // The partial chunks (at most two per destination): one wave, lane = (destination,
-        // end), so that the divergent byte work runs once per tile and not once per unit.
-        if (w != WORKERS - 1) return;
-        for (uint32_t it = (uint32_t) lane; it < 2u * P; it += 64u) {
-            const uint32_t b = it >> 1;
-            const unsigned long long G = gaddr2[pr * OS_MAXP + b];
-            const uint32_t nb = nbytes2[pr * OS_MAXP + b];
-            if (nb == 0) continue;
-            const uint32_t nch = (uint32_t) (((G & 15ull) + nb + 15ull) >> 4);
-            if ((it & 1u) && nch == 1) continue; // the only chunk is taken as the first
-            const unsigned long long g0 = (G & ~15ull) + ((it & 1u) ? (unsigned long long) (nch - 1u) << 4 : 0ull);
-            if (g0 >= G && g0 + 16 <= G + nb) continue; // a whole chunk: stored above
-            // naturally aligned pieces, growing from the first byte, then shrinking towards the last
-            const uint8_t *src0 = sout + dstart2[pr * OS_MAXP + b];
-            unsigned long long ga = g0 > G ? g0 : G;
-            const unsigned long long gb = g0 + 16 < G + nb ? g0 + 16 : G + nb;
-            if ((ga & 1) && ga + 1 <= gb) {
-                *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
-                ga += 1;
-            }
-            if ((ga & 2) && ga + 2 <= gb) {
-                *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
-                ga += 2;
-            }
-            if ((ga & 4) && ga + 4 <= gb) {
-                *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
-                ga += 4;
-            }
-            if (ga + 8 <= gb) {
-                *reinterpret_cast<unsigned long long *>(ga) = reinterpret_cast<const OvU64 *>(src0 + (ga - G))->v;
-                ga += 8;
-            }
-            if (ga + 4 <= gb) {
-                *reinterpret_cast<uint32_t *>(ga) = reinterpret_cast<const OvU32 *>(src0 + (ga - G))->v;
-                ga += 4;
-            }
-            if (ga + 2 <= gb) {
-                *reinterpret_cast<uint16_t *>(ga) = reinterpret_cast<const OvU16 *>(src0 + (ga - G))->v;
-                ga += 2;
-            }
-            if (ga + 1 <= gb) *reinterpret_cast<uint8_t *>(ga) = src0[ga - G];
+        if (u < utotal) {
+            const Unit t0 = unit(u);
+            write_chunk(t0, read_chunk(t0));
         }
+        if (with_partials && w == WORKERS - 1) store_partials(pr);
     };
     // n <= 16 bytes out of four registers to any address of the image
     auto put = [&](uint8_t *o, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t n) {
@@ -719,7 +752,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         // trip): in flight during the store and the reorder
         uint32_t nx[K][4];
         if (PRE) issue_q0(fn, nx); // (offsets of a tile that does not exist are all zero: nothing is loaded)
-        if (have_prev) store_image(par ^ 1);
+        if (have_prev) store_image(par ^ 1, false);
         OSR_PHASE(3)
         __syncthreads(); // B: the image is free
         OSR_PHASE(4)
@@ -822,8 +855,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         par ^= 1;
     }
     __syncthreads(); // tables of the last tile are ready
-    if (have_prev) store_image(par ^ 1);
-    if ((VAR & OSV_STATS) && wt == 0) {
+    if (have_prev) store_image(par ^ 1, true);
+    // (OSV_NO_PREFETCH has no other meaning here: with it the last worker wave reports)
+    if ((VAR & OSV_STATS) && wt == ((VAR & OSV_NO_PREFETCH) ? WT - 64 : 0)) {
 #pragma unroll
         for (int i = 0; i < 8; i++) atomicAdd(&p.ctrl->head.stats[i], ph[i]);
     }

@@ -25,6 +25,7 @@ const OsrEntry kOsr[] = {
     // diagnostic builds: cycles per phase
     OSR(4, 2, 1, false, false, OSV_STATS), OSR(3, 2, 1, false, true, OSV_STATS), OSR(4, 2, 2, true, false, OSV_STATS),
     OSR(4, 1, 2, true, true, OSV_STATS),
+    OSR(4, 2, 1, false, false, OSV_STATS | OSV_NO_PREFETCH), OSR(4, 2, 1, false, false, OSV_STATS | OSV_FAKE_CHAIN),
     // timing only (wrong output): no chained scan, positions are made up -- prices the chain
     OSR(4, 2, 1, false, false, OSV_FAKE_CHAIN), OSR(3, 2, 1, false, true, OSV_FAKE_CHAIN), OSR(4, 2, 2, true, false, OSV_FAKE_CHAIN),
 };
