@@ -17,6 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "libmimir_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libmimir_ref.so")
+REF_SER_SO = os.path.join(_HERE, "_ref", "libmimir_ref_ser.so")
 
 KEY_FIXED, KEY_CSTR = 0, 1
 VAL_VOID, VAL_FIXED, VAL_CSTR = 0, 1, 2
@@ -68,6 +69,8 @@ class Oracle:
         L.mo_geometry.restype = C.c_int
         L.mo_geometry.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mo_key_len.restype = C.c_int64
+        L.mo_key_len.argtypes = [C.POINTER(Layout), C.c_void_p, C.c_int64]
         L.mo_dest.restype = C.c_int
         L.mo_dest.argtypes = [C.POINTER(Layout), C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p,
@@ -335,3 +338,66 @@ class Reference:
     def kv_cstr_blob16(self, key: bytes, val16: bytes, cap=4096):
         v = C.create_string_buffer(bytes(val16), 16)
         return self._call(self.L.ref_kv_cstr_blob16, key, v, cap=cap)
+
+
+class ReferenceSerializer:
+    """The reference's own Serializer<K,V>::kv_to_bytes / get_hash_code
+    (oracle/_ref/libmimir_ref_ser.so, built from oracle/ref_probe_ser.cpp)."""
+
+    def __init__(self):
+        build()
+        if not os.path.exists(REF_SER_SO):
+            raise FileNotFoundError(REF_SER_SO)
+        L = C.CDLL(REF_SER_SO)
+        L.ser_kv_cstr_u64.restype = C.c_int
+        L.ser_kv_cstr_u64.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]
+        L.ser_hash_cstr.restype = C.c_uint32
+        L.ser_hash_cstr.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.ser_kv_u64_u64.restype = C.c_int
+        L.ser_kv_u64_u64.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        L.ser_hash_u64.restype = C.c_uint32
+        L.ser_hash_u64.argtypes = [C.c_uint64]
+        L.ser_kv_chars_u64.restype = C.c_int
+        L.ser_kv_chars_u64.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]
+        L.ser_hash_chars.restype = C.c_uint32
+        L.ser_hash_chars.argtypes = [C.c_char_p, C.c_int]
+        L.ser_kv_cstr_blob16.restype = C.c_int
+        L.ser_kv_cstr_blob16.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.L = L
+
+    @staticmethod
+    def _run(fn, args, bufsize, room=4096):
+        """kv_to_bytes into a buffer of `room` bytes (filled with 0xEE) that the call is told
+        holds `bufsize`: -> (return value, the bytes it wrote = the prefix that changed)."""
+        buf = C.create_string_buffer(b"\xee" * room, room)
+        rc = fn(*args, buf, bufsize)
+        raw = buf.raw
+        written = room
+        while written > 0 and raw[written - 1] == 0xEE:
+            written -= 1
+        return rc, raw[:written]
+
+    def kv_to_bytes(self, shape, key, val, bufsize, keycount=1):
+        """shape: "cstr_u64" (key: bytes, or a pair of bytes with keycount 2), "u64_u64",
+        "chars_u64" (keycount characters of key), "cstr_blob16" (val: 16 bytes)."""
+        if shape == "cstr_u64":
+            k0, k1 = (key, None) if keycount == 1 else key
+            return self._run(self.L.ser_kv_cstr_u64, (k0, k1, keycount, val), bufsize)
+        if shape == "u64_u64":
+            return self._run(self.L.ser_kv_u64_u64, (key, val), bufsize)
+        if shape == "chars_u64":
+            return self._run(self.L.ser_kv_chars_u64, (key, keycount, val), bufsize)
+        if shape == "cstr_blob16":
+            v = C.create_string_buffer(bytes(val), 16)
+            return self._run(self.L.ser_kv_cstr_blob16, (key, v), bufsize)
+        raise ValueError(shape)
+
+    def hash_code(self, shape, key, keycount=1):
+        if shape in ("cstr_u64", "cstr_blob16"):
+            k0, k1 = (key, None) if keycount == 1 else key
+            return self.L.ser_hash_cstr(k0, k1, keycount)
+        if shape == "u64_u64":
+            return self.L.ser_hash_u64(key)
+        if shape == "chars_u64":
+            return self.L.ser_hash_chars(key, keycount)
+        raise ValueError(shape)

@@ -26,3 +26,13 @@ def reference():
         return o.Reference()
     except (FileNotFoundError, OSError):
         pytest.skip("oracle/_ref/libmimir_ref.so not built (no /root/reference)")
+
+
+@pytest.fixture(scope="session")
+def reference_serializer():
+    """The reference's own Serializer<K,V>::kv_to_bytes / get_hash_code, where available."""
+    from oracle import oracle as o
+    try:
+        return o.ReferenceSerializer()
+    except (FileNotFoundError, OSError):
+        pytest.skip("oracle/_ref/libmimir_ref_ser.so not built (no /root/reference or no MPI library)")

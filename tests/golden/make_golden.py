@@ -17,7 +17,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle.oracle import Reference  # noqa: E402
+from oracle.oracle import Reference, ReferenceSerializer  # noqa: E402
 
 
 def main():
@@ -130,6 +130,42 @@ def main():
                              "(src/serializer.h:54-61, :100-129, :376-416; src/collectiveshuffler.h:563-585)",
                    "vectors": parse}, f, indent=0)
     print(f"wrote {len(parse)} parse vectors")
+    # 5. the pack side's two Serializer methods themselves: kv_to_bytes (return value and the
+    #    bytes written at buffer sizes around the key's and the record's length: the "-1 iff
+    #    it does not fit" rule that ends a round) and get_hash_code (what get_target_rank
+    #    takes modulo the rank count), for the record shapes of the examples.
+    ser = ReferenceSerializer()
+    val16 = bytes([0xbb, 0, 0, 0, 0, 0, 0, 0]) + (77).to_bytes(8, "little")
+    cases = [("cstr_u64", b"a", 1, 1), ("cstr_u64", b"hello", 0x0102030405060708, 1),
+             ("cstr_u64", b"w" * 40, 7, 1), ("cstr_u64", (b"left", b"right"), 3, 2),
+             ("cstr_u64", (b"", b"x"), 3, 2),
+             ("u64_u64", 0, 0, 1), ("u64_u64", 0xdeadbeefcafef00d, 5, 1),
+             ("chars_u64", octkey, 1, 1), ("chars_u64", octkey, 1, 4), ("chars_u64", octkey, 1, 8),
+             ("chars_u64", octkey, 1, 12), ("chars_u64", octkey, 1, 15),
+             ("cstr_blob16", b"k", val16, 1), ("cstr_blob16", b"joinkey", val16, 1)]
+    pack = []
+    for shape, key, val, kc in cases:
+        rc_full, rec = ser.kv_to_bytes(shape, key, val, 4096, keycount=kc)
+        R = len(rec)
+        assert rc_full == R
+        vb = 16 if shape == "cstr_blob16" else 8
+        klen = R - vb
+        fits = []
+        for bufsize in sorted({0, max(klen - 1, 0), klen, klen + 1, R - 1, R, R + 1}):
+            rc, wrote = ser.kv_to_bytes(shape, key, val, bufsize, keycount=kc)
+            fits.append({"bufsize": bufsize, "ret": rc, "written_hex": wrote.hex()})
+        def enc(x):
+            if isinstance(x, tuple):
+                return [e.hex() for e in x]
+            return x.hex() if isinstance(x, (bytes, bytearray)) else x
+        pack.append({"shape": shape, "key": enc(key), "val": enc(val), "keycount": kc,
+                     "record_hex": rec.hex(), "key_bytes": klen,
+                     "hash_code": ser.hash_code(shape, key, keycount=kc), "fits": fits})
+    with open(os.path.join(HERE, "pack_vectors.json"), "w") as f:
+        json.dump({"source": "Serializer<K,V>::kv_to_bytes (src/serializer.h:348-364) and get_hash_code "
+                             "(:464-480), called through oracle/ref_probe_ser.cpp",
+                   "vectors": pack}, f, indent=0)
+    print(f"wrote {len(pack)} pack vectors")
     print(f"wrote {len(vectors)}+{len(seeded)} hash vectors, {len(wire)} wire vectors, {len(tok)} texts")
 
 

@@ -633,3 +633,65 @@ def test_two_string_keys_with_fixed_value(oracle):
             so = int(want["send_offset"][p])
             assert np.array_equal(img[p * buf:p * buf + so], want["partitions"][p])
         pk.close()
+
+
+def test_pack_vectors_boundary_sizes_on_device():
+    """tests/golden/pack_vectors.json (the reference's own Serializer::kv_to_bytes and
+    get_hash_code): a record goes into a partition with `bufsize` bytes left iff the
+    reference's call returned its length rather than -1 (exact fit succeeds, one byte less
+    ends the round, src/collectiveshuffler.h:143-162), it lands as the reference wrote it,
+    and its destination is the reference's hash code modulo the rank count."""
+    import json
+    import os
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pack_vectors.json")) as f:
+        vectors = json.load(f)["vectors"]
+    dev = torch.device("cuda:0")
+    algos = set()
+    for v in vectors:
+        if v["shape"] == "cstr_u64":
+            glay = capi.Layout.make(capi.KEY_CSTR, 0, capi.VAL_FIXED, 8, key_count=v["keycount"])
+        elif v["shape"] == "u64_u64":
+            glay = capi.Layout.make(capi.KEY_FIXED, 8, capi.VAL_FIXED, 8)
+        elif v["shape"] == "chars_u64":
+            glay = capi.Layout.make(capi.KEY_FIXED, v["keycount"], capi.VAL_FIXED, 8)
+        else:
+            glay = capi.Layout.make(capi.KEY_CSTR, 0, capi.VAL_FIXED, 16)
+        rec = np.frombuffer(bytes.fromhex(v["record_hex"]), dtype=np.uint8)
+        R = len(rec)
+        d_rec = torch.from_numpy(rec.copy()).to(dev)
+        d_off = None if glay.fixed_len() else torch.tensor([0, R], dtype=torch.int32, device=dev)
+        # (16-byte records take the 16-byte kernel only with 16-byte aligned fills: both paths are seen)
+        for P in (1, 7):
+            want_d = v["hash_code"] % P
+            buf = 64
+            pk = DevicePacker(glay, P, -1, buf, max_records=1)
+            for f in v["fits"]:
+                init = np.full(P, buf - f["bufsize"], dtype=np.int64)
+                image = torch.full((P * buf,), 0xEE, dtype=torch.uint8, device=dev)
+                dest = torch.full((1,), 0xFF, dtype=torch.uint8, device=dev)
+                got = pk.pack(d_rec, 1, image, rec_off=d_off, init_offset=init, dest_out=dest)
+                algos.add(pk.last_kernel())
+                assert (got.next == 1) == (f["ret"] != -1), (v["shape"], v["key"], f, pk.last_kernel())
+                if f["ret"] != -1:
+                    at = want_d * buf + buf - f["bufsize"]
+                    img = image.cpu().numpy()
+                    assert img[at:at + R].tobytes() == rec.tobytes(), (v["shape"], v["key"], f)
+                    assert int(got.send_offset[want_d]) == buf - f["bufsize"] + R
+                    assert int(dest.cpu()[0]) == want_d
+            pk.close()
+        # a partition of exactly the record's size takes it; one byte smaller can never take it
+        pk = DevicePacker(glay, 1, -1, R, max_records=1)
+        image = torch.full((R,), 0xEE, dtype=torch.uint8, device=dev)
+        assert pk.pack(d_rec, 1, image, rec_off=d_off).next == 1
+        assert image.cpu().numpy().tobytes() == rec.tobytes()
+        pk.close()
+        if R > 1:
+            pk = DevicePacker(glay, 1, -1, R - 1, max_records=1)
+            image = torch.full((R,), 0xEE, dtype=torch.uint8, device=dev)
+            with pytest.raises(capi.MgsError) as ei:
+                pk.pack(d_rec, 1, image, rec_off=d_off)
+            assert ei.value.status == capi.ERR_RECORD_SIZE
+            pk.close()
+    assert {"k_onesweepv", "k_onesweepr"} <= algos, algos

@@ -49,6 +49,8 @@ def test_noalloc_equals_pack_device_twice(kind, P, rank):
             return datagen.word_records(n, n_unique=2000, alpha=1.0, len_mean=6, len_sd=1, seed=seed)
         return datagen.octree_records(n, level=12, seed=seed)
 
+    from oracle import oracle as O
+    orc = O.Oracle()
     _, _, lay_t = make(16, 1)
     lay = capi.Layout.make(*lay_t)
     for i, n in enumerate(sizes):
@@ -58,6 +60,11 @@ def test_noalloc_equals_pack_device_twice(kind, P, rank):
         pk2 = DevicePacker(lay, P, rank, buf, max_records=sizes[0])
         r = _both(pk2, blob, offs, n, P, rank, buf)
         assert r.next == n
+        # ... and the no-allocation call against the oracle itself
+        want = orc.pack_round(O.Layout.make(*lay_t), blob, offs, n, 0, P, rank, buf, want_bytes=False)
+        assert r.next == want["next"] and r.send_offset.tolist() == want["send_offset"].tolist()
+        assert (r.packed_records, r.local_records, r.local_bytes) == \
+            (want["packed_records"], want["local_records"], want["local_bytes"])
         pk2.close()
         small = (len(blob) // P // 3) // 16 * 16
         pk3 = DevicePacker(lay, P, rank, small, max_records=sizes[0])
