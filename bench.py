@@ -157,6 +157,56 @@ def host_cpus():
     return {"logical": logical, "physical": physical, "share": share}
 
 
+def exchange_sums(view16):
+    """(records, wrap-around sum of the key words, of the value words) of a run of <u64,u64> records."""
+    import torch
+    if view16.numel() == 0:
+        return [0, 0, 0]
+    w = view16.view(torch.int64).view(-1, 2)
+    return [int(w.shape[0]), int(w[:, 0].sum().item()), int(w[:, 1].sum().item())]
+
+
+def verify_exchange(dist, torch, np, capi, DevicePacker, lay, P, me, streams, stream_cap, so_tot, recv, recv_cap,
+                    recv_tot, dev, backend):
+    """The exchange of one step, end to end (16-byte <u64,u64> records): what every source says
+    it sent to this rank -- record count and wrap-around sums of keys and values -- is what
+    arrived from it; every record that arrived belongs here by the library's own hash (the
+    received stream packed again for P destinations lands in partition `me` alone); and a
+    source's records arrive in its emit order (the value is the emit index).  Returns a dict
+    for the bench line; raises on a mismatch."""
+    mine = torch.zeros((P, 3), dtype=torch.int64)
+    for d in range(P):
+        if d != me:
+            mine[d] = torch.tensor(exchange_sums(streams[d * stream_cap:d * stream_cap + int(so_tot[d])]))
+    everyone = [torch.zeros((P, 3), dtype=torch.int64, device=dev if backend == "nccl" else "cpu") for _ in range(P)]
+    dist.all_gather(everyone, mine.to(everyone[0].device))
+    checked = 0
+    for s in range(P):
+        if s == me:
+            continue
+        nbytes = int(recv_tot[s])
+        got = recv[s * recv_cap:s * recv_cap + nbytes]
+        want = everyone[s][me].cpu().tolist()
+        have = exchange_sums(got)
+        if have != want:
+            raise RuntimeError(f"rank {me}: from source {s} arrived (records, key sum, value sum) {have}, it sent {want}")
+        if nbytes:
+            vals = got.view(torch.int64).view(-1, 2)[:, 1]
+            if not bool((vals[1:] > vals[:-1]).all().item()):
+                raise RuntimeError(f"rank {me}: records of source {s} are not in its emit order")
+            chk = DevicePacker(lay, P, -1, nbytes, max_records=nbytes // 16, device=dev)
+            img = torch.empty(P * nbytes, dtype=torch.uint8, device=f"cuda:{dev}")
+            res = chk.pack(got, nbytes // 16, img)
+            chk.close()
+            del img
+            if int(res.send_offset[me]) != nbytes or int(res.send_offset.sum()) != nbytes:
+                raise RuntimeError(f"rank {me}: records from source {s} that hash to another rank arrived")
+        checked += have[0]
+    return {"verified": True, "records_checked": checked,
+            "checks": "per (source, destination) pair: record count, wrap-around key and value sums as sent = as "
+                      "received; destination of every received record = this rank; values of a source increasing"}
+
+
 def parse_size(text):
     """Sizes as MIMIR_COMM_SIZE takes them (src/mimir.cpp:75-131): a number with an
     optional b/k/m/g suffix."""
@@ -192,6 +242,18 @@ def main():
                          "going on in the same destination streams where the one before stopped (stream_fill / "
                          "open_round_base) -- a step of chunks x records records.  Variable-width batches stay "
                          "under 4 GiB (32-bit record offsets); this is how 1e8..1e9 of them are packed.")
+    ap.add_argument("--split", type=int, default=0,
+                    help="N > 1, streams layout: the batch is packed in this many calls of records / split records "
+                         "each, every call going on in the same streams (the result is that of one call), and what "
+                         "a call has finished -- the rounds it cut -- travels while the next call packs "
+                         "(StreamWindowExchange on a stream of its own).  Default: 4 for N > 1; 1 = pack everything, "
+                         "then exchange.")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: one more, untimed step whose exchange is checked end to end: record counts and "
+                         "wrap-around sums of keys and values per (source, destination) pair as sent and as "
+                         "received, every received record's destination (the library's own hash) = this rank, "
+                         "values of a source in emit order.  On by default for the u64 workload.")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--exchange", default="batch", choices=["batch", "rounds"],
                     help="N > 1, streams layout: batch = everything a destination gets from this rank in the "
                          "whole batch as ONE message (its rounds lie back to back in the stream; the rounds come "
@@ -293,7 +355,12 @@ def main():
         # batch: one receive stream per source; else one receive image per round
         recv = torch.empty(P * stream_cap if batch_exchange else max_rounds * stride, dtype=torch.uint8,
                            device=f"cuda:{dev}")
-        from mimir_amd.exchange import exchange_rounds, exchange_streams
+        from mimir_amd.exchange import StreamWindowExchange, exchange_rounds, exchange_streams
+    split = 1
+    if distributed and streams_layout and args.exchange == "batch" and chunks == 1:
+        split = args.split if args.split > 0 else 4
+        split = max(1, min(split, n))
+    comm_stream = torch.cuda.Stream(device=dev) if (distributed and backend == "nccl") else None
 
     kernel_ms, pack_s, stats = [], [], {"sent_max": 0, "rounds": 0, "exchanges": 0}
 
@@ -302,11 +369,22 @@ def main():
         if streams_layout:
             from mimir_amd.packer import merge_stream_rounds
             r, fill, base, lused, kms = None, None, None, 0, 0.0
-            for _ in range(chunks):
-                rc_ = pk.pack_streams(records, n, images, stream_cap, max_rounds, rec_off=rec_off, stream_fill=fill,
-                                      open_round_base=base, local_out=None if local is None else local[lused:])
-                if rc_.next != n:
-                    raise RuntimeError(f"{rc_.n_rounds} rounds used up at record {rc_.next} of {n}: raise max_rounds")
+            calls = [(0, n)] * chunks if split == 1 else [(i * n // split, (i + 1) * n // split) for i in range(split)]
+            windows = None
+            if split > 1:
+                # what a call has finished travels while the next call packs
+                dst = torch.empty(recv.shape, dtype=torch.uint8) if backend == "gloo" else recv
+                windows = StreamWindowExchange(dst, stream_cap, comm_stream=comm_stream)
+                sent = np.zeros(P, dtype=np.int64)
+            t_pack = 0.0
+            for ci, (a, b) in enumerate(calls):
+                tp = time.perf_counter()
+                rc_ = pk.pack_streams(records, b, images, stream_cap, max_rounds, start=a, rec_off=rec_off,
+                                      stream_fill=fill, open_round_base=base,
+                                      local_out=None if local is None else local[lused:])
+                t_pack += time.perf_counter() - tp
+                if rc_.next != b:
+                    raise RuntimeError(f"{rc_.n_rounds} rounds used up at record {rc_.next} of {b}: raise max_rounds")
                 kms += pk.last_kernel_ms()
                 lused += rc_.local_bytes
                 base = rc_.round_base[-1].copy()
@@ -314,9 +392,23 @@ def main():
                 if self_rank >= 0:
                     fill[self_rank] = 0
                 r = merge_stream_rounds(r, rc_)
-            pack_s.append(time.perf_counter() - t0)
+                if windows is not None:
+                    # the rounds this call cut are final; its last round is still open unless it was the last call
+                    hi = fill if ci == len(calls) - 1 else base
+                    hi = np.maximum(hi, sent)
+                    windows.post(images, stream_cap, sent, hi)
+                    sent = hi.copy()
+            pack_s.append(t_pack if windows is not None else time.perf_counter() - t0)
             kernel_ms.append(kms)
             stats["rounds"] = r.n_rounds
+            if windows is not None:
+                rcw, rbw, R = windows.finish(r.round_send_offset)
+                if backend == "gloo":
+                    recv.copy_(dst)
+                stats["exchanges"] = R
+                stats["sent_max"] = max(stats["sent_max"], int(r.round_send_offset.sum(axis=0).max()))
+                stats["last"] = (r, rcw, rbw)
+                return r
         else:
             r = pk.pack_rounds(records, n, images, stride, max_rounds, rec_off=rec_off, local_out=local, algo=algo)
             pack_s.append(time.perf_counter() - t0)
@@ -330,7 +422,8 @@ def main():
             src_img = images.cpu() if backend == "gloo" else images   # gloo rehearsal: through host memory
             dst_img = torch.empty(recv.shape, dtype=torch.uint8) if backend == "gloo" else recv
             if batch_exchange:
-                rc, _, R = exchange_streams(src_img, stream_cap, so, bases, dst_img, stream_cap)
+                rc, rb, R = exchange_streams(src_img, stream_cap, so, bases, dst_img, stream_cap)
+                stats["last"] = (r, rc, rb)
             else:
                 rc, R = exchange_rounds(src_img, stride, so, part, dst_img, stride, round_base=bases)
             if backend == "gloo":
@@ -359,6 +452,63 @@ def main():
                          device="cpu" if backend == "gloo" else f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- N > 1, after the timed region: the two exchange protocols side by side, what the
+    # overlap hid, and the end-to-end check of what arrived
+    extra = {}
+    if distributed and streams_layout and "last" in stats:
+        r_last = stats["last"][0]
+        so_l, base_l = r_last.round_send_offset, r_last.round_base
+        src_img = images.cpu() if backend == "gloo" else images
+
+        def timed(fn, reps=2):
+            best = None
+            for _ in range(reps):
+                barrier()
+                t1 = time.perf_counter()
+                fn()
+                barrier()
+                d1 = time.perf_counter() - t1
+                best = d1 if best is None else min(best, d1)
+            tt = torch.tensor([best], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{dev}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) * 1e3
+
+        dst_b = torch.empty(recv.shape, dtype=torch.uint8) if backend == "gloo" else recv
+        extra["batch_ms"] = timed(lambda: exchange_streams(src_img, stream_cap, so_l, base_l, dst_b, stream_cap))
+        rounds_bytes = (int(so_l.shape[0]) + 8) * stride
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        if backend == "gloo" or rounds_bytes < free_b // 2:
+            dst_r = torch.empty(rounds_bytes, dtype=torch.uint8, device="cpu" if backend == "gloo" else f"cuda:{dev}")
+            rmax = torch.tensor([so_l.shape[0]], dtype=torch.int64, device=dst_r.device)
+            dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+            if int(rmax.item()) + 1 <= rounds_bytes // stride:
+                extra["rounds_ms"] = timed(lambda: exchange_rounds(src_img, stride, so_l, stream_cap, dst_r, stride,
+                                                                   round_base=base_l))
+            del dst_r
+        verify = (args.verify or args.workload == "u64") and not args.no_verify and args.workload == "u64"
+        if verify:
+            # one more exchange of the last step's streams into a cleared receive buffer
+            recv.zero_()
+            dst_v = torch.empty(recv.shape, dtype=torch.uint8) if backend == "gloo" else recv
+            rc_v, _, _ = exchange_streams(src_img, stream_cap, so_l, base_l, dst_v, stream_cap)
+            if backend == "gloo":
+                recv.copy_(dst_v)
+            extra.update(verify_exchange(dist, torch, np, capi, DevicePacker, lay, P, rank, images, stream_cap,
+                                         so_l.sum(axis=0), recv, stream_cap, rc_v.sum(axis=0), dev, backend))
+            # ... and the windows of the timed steps delivered the same bytes: the last timed
+            # step's receive streams were overwritten above, so compare a fresh windowed step
+            if split > 1:
+                keep = recv.clone()
+                step()
+                torch.cuda.synchronize()
+                for s_ in range(P):
+                    nb_ = int(rc_v[:, s_].sum())
+                    if s_ != rank and not torch.equal(keep[s_ * stream_cap:s_ * stream_cap + nb_],
+                                                      recv[s_ * stream_cap:s_ * stream_cap + nb_]):
+                        raise RuntimeError(f"rank {rank}: the windowed exchange delivered other bytes from source {s_}")
+                extra["windows_equal_batch"] = True
+                del keep
 
     ms_per_step = dt / args.steps * 1e3
     value = n * chunks * world * args.steps / dt
@@ -412,13 +562,24 @@ def main():
         out["pack_only_records_per_s"] = pack_only
         xfer_s = dt / args.steps - sum(pack_s) / len(pack_s)
         hot = stats["sent_max"]   # bytes of the busiest (this rank -> peer) pair over the whole step
+        if split > 1:
+            messages = (f"the batch is packed in {split} calls; what a call has finished travels, one message per "
+                        "(source, destination) pair, while the next call packs; the rounds are views on both sides")
+        elif batch_exchange:
+            messages = "one per (source, destination) pair for the whole batch; the rounds are views on both sides"
+        else:
+            messages = "one grouped send/recv batch per round"
         out["exchange"] = {"exchanges": stats["exchanges"],
-                           "messages": ("one per (source, destination) pair for the whole batch; the rounds are views "
-                                        "on both sides" if batch_exchange else "one grouped send/recv batch per round"),
+                           "messages": messages, "split": split,
                            "hottest_pair_bytes": hot,
                            "exchange_ms": xfer_s * 1e3,
                            "xgmi_floor_ms": hot / (XGMI_LINK_GBS * 1e9) * 1e3,
                            "frac_of_xgmi_pair_roofline": (hot / (XGMI_LINK_GBS * 1e9)) / max(xfer_s, 1e-9)}
+        out["exchange"].update(extra)
+        if "batch_ms" in extra:
+            # pack alone + the whole batch as one exchange, against the step as it ran
+            serial_ms = sum(pack_s) / len(pack_s) * 1e3 + extra["batch_ms"]
+            out["exchange"]["overlap_ms_hidden"] = max(0.0, serial_ms - ms_per_step) if split > 1 else 0.0
     if rank == 0 and not distributed and not args.no_cpu_baseline and args.workload == "u64":
         del images
         torch.cuda.empty_cache()

@@ -207,3 +207,117 @@ def exchange_streams(streams, stream_cap, round_send_offset, round_base, recv_st
         if streams.is_cuda:
             torch.cuda.current_stream(dev).synchronize()
     return recv_count, recv_base, R
+
+
+class StreamWindowExchange:
+    """The all-to-all-v of a streams-layout batch in pieces, so that it overlaps with the
+    packing that is still going on (the reference's overlap model is NBCollectiveShuffler,
+    src/nbcollectiveshuffler.h:139-183, :222-387: pack into one buffer while others travel).
+
+    The destination streams only ever grow at their ends, and a round that the packer has
+    cut is final.  After every pack call the bytes of each stream that belong to finished
+    rounds and have not travelled yet -- a window [lo, hi) per destination -- are posted
+    here: their sizes go out in one small all-to-all (the counts exchange of
+    src/collectiveshuffler.h:606-607, for a whole window), then one point-to-point message
+    per (source, destination) pair, appended to the receiver's stream for that source.  The
+    rounds stay views on both sides, exactly as in exchange_streams: the per-round counts are
+    exchanged once at the end (finish), and what source s sent in its round k is bytes
+    [recv_base[k, s], + recv_count[k, s]) of receive stream s.
+
+    post() returns at once; the transfers of a window are waited for by the next post() or by
+    finish() (one window in flight)."""
+
+    def __init__(self, recv_streams, recv_cap, group=None, comm_stream=None):
+        self.group = group
+        self.P = dist.get_world_size(group)
+        self.me = dist.get_rank(group)
+        self.recv = recv_streams
+        self.recv_cap = int(recv_cap)
+        self.fill = [0] * self.P          # bytes received so far from each source
+        self.works = []
+        self.keep = []                    # host copies in flight (gloo)
+        self.sent = [0] * self.P          # bytes posted so far to each destination
+        # on GPUs the transfers are enqueued on a stream of their own, so that the pack
+        # kernels enqueued meanwhile do not wait behind them
+        self.comm_stream = comm_stream
+
+    def _peer(self, r):
+        return dist.get_global_rank(self.group, r) if self.group else r
+
+    def _drain(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.keep = []
+        if self.comm_stream is not None:
+            self.comm_stream.synchronize()
+
+    def post(self, streams, stream_cap, lo, hi):
+        """Send bytes [lo[d], hi[d]) of stream d (at streams[d * stream_cap:]) to rank d."""
+        self._drain()
+        P, me = self.P, self.me
+        dev = self.recv.device
+        sizes = [0 if d == me else max(0, int(hi[d]) - int(lo[d])) for d in range(P)]
+        ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _NullCtx()
+        with ctx:
+            if self.comm_stream is not None:
+                # what is sent was written by kernels of the caller's stream
+                self.comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            send = torch.tensor(sizes, dtype=torch.int64, device=dev)
+            got = torch.empty_like(send)
+            dist.all_to_all_single(got, send, group=self.group)
+            got = got.cpu().tolist()
+            ops = []
+            for s in range(P):
+                rc = int(got[s])
+                if s == me or rc == 0:
+                    continue
+                if self.fill[s] + rc > self.recv_cap:
+                    raise ValueError(f"receive stream of source {s} needs {self.fill[s] + rc} bytes, has {self.recv_cap}")
+                o = s * self.recv_cap + self.fill[s]
+                ops.append(dist.P2POp(dist.irecv, self.recv[o:o + rc], self._peer(s), group=self.group))
+                self.fill[s] += rc
+            for d in range(P):
+                if sizes[d] == 0:
+                    continue
+                o = d * int(stream_cap) + int(lo[d])
+                piece = streams[o:o + sizes[d]]
+                if piece.device != dev:       # gloo rehearsal: the streams live on the GPU
+                    piece = piece.to(dev)
+                    self.keep.append(piece)
+                ops.append(dist.P2POp(dist.isend, piece, self._peer(d), group=self.group))
+                self.sent[d] += sizes[d]
+            if ops:
+                self.works = dist.batch_isend_irecv(ops)
+
+    def finish(self, round_send_offset):
+        """Wait for the last window and exchange the per-round counts (as exchange_streams
+        does).  Returns (recv_count int64 [R, P], recv_base int64 [R, P], R)."""
+        import numpy as np
+        self._drain()
+        P = self.P
+        dev = self.recv.device
+        so = np.asarray(round_send_offset, dtype=np.int64).reshape(-1, P)
+        rmax = torch.tensor([so.shape[0]], dtype=torch.int64, device=dev)
+        dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)
+        R = int(rmax.item())
+        full = np.zeros((R, P), dtype=np.int64)
+        full[:so.shape[0]] = so
+        send = torch.from_numpy(np.ascontiguousarray(full.T)).to(dev)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        recv_count = recv.cpu().numpy().T.copy()
+        recv_base = np.cumsum(recv_count, axis=0) - recv_count
+        for s in range(P):
+            if s != self.me and int(recv_count[:, s].sum()) != self.fill[s]:
+                raise RuntimeError(f"source {s}: {self.fill[s]} bytes arrived, its rounds add up to "
+                                   f"{int(recv_count[:, s].sum())}")
+        return recv_count, recv_base, R
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

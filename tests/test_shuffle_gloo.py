@@ -119,9 +119,12 @@ def run_case(oracle, P, kind, comm, use_gpu=False, min_rounds=3, counts=None, co
     assert total == sum(counts) or combine_op is not None
 
 
-@pytest.mark.parametrize("P,kind", [(2, "u64"), (2, "words"), (3, "join"), (4, "oct")])
+@pytest.mark.parametrize("P,kind", [(2, "u64"), (2, "words"), (3, "join"), (4, "oct"), (8, "words"), (8, "oct")])
 def test_shuffle_matches_reference_simulation(oracle, P, kind):
-    run_case(oracle, P, kind, comm=16384)
+    # (P = 8: 4 KiB partitions, the geometry step that three of the five benchmark configurations
+    # take at full scale -- src/collectiveshuffler.h:33-53)
+    counts = None if P < 8 else [0 if r == 1 else 1500 * (r % 3 + 1) + 37 * r for r in range(P)]
+    run_case(oracle, P, kind, comm=16384 if P < 8 else 32768, counts=counts)
 
 
 @pytest.mark.parametrize("P,comm", [(2, 4096), (3, 6144), (4, 4096)])
@@ -207,6 +210,6 @@ def run_nb_case(oracle, P, kind, use_gpu=False):
         assert 2 <= got[r]["buffers"] <= 5
 
 
-@pytest.mark.parametrize("P,kind", [(2, "words"), (3, "u64"), (4, "join")])
+@pytest.mark.parametrize("P,kind", [(2, "words"), (3, "u64"), (4, "join"), (8, "u64")])
 def test_nonblocking_shuffler_matches_reference_rounds(oracle, P, kind):
     run_nb_case(oracle, P, kind)
