@@ -200,7 +200,12 @@ int mgs_pack_device(mgs_handle *h, const void *d_records,
  * mgs_pack_result() then waits for that work and fetches the result.  One
  * pack call may be in flight per handle; until its result has been fetched
  * the handle's other device calls (unpack, tokenize, group, combine) return
- * MGS_ERR_STATE, and another mgs_pack_device[_async] first waits for it. */
+ * MGS_ERR_STATE, and another mgs_pack_device[_async] first waits for it.
+ * (Callers that used to rely on unpack/tokenize/group/combine waiting for a
+ * pack in flight call mgs_pack_result first.)  A call that packs several
+ * rounds answers only to its own result call: mgs_pack_result on it returns
+ * MGS_ERR_STATE and leaves it in flight, so mgs_pack_rounds_result /
+ * mgs_pack_streams_result still fetch it. */
 int mgs_pack_device_async(mgs_handle *h, const void *d_records,
                           const uint32_t *d_rec_off, uint64_t n_end,
                           uint64_t start, const int64_t *init_offset,
@@ -323,9 +328,11 @@ int mgs_pack_streams_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next
                             uint64_t *round_local_records,
                             int64_t *round_local_bytes);
 
-/* mgs_pack_device for callers that cannot allocate: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
- * counterpart in the reference.  Same arguments, same kernels and same result
+/* mgs_pack_device for callers that cannot allocate: tight serving loops,
+ * harnesses that forbid hipMalloc, code that must not grow the process's device
+ * memory.  (It is a blocking call -- it ends by waiting for the stream and
+ * reading the result back -- so it is not for use under HIP graph capture.)  It
+ * has no counterpart in the reference.  Same arguments, same kernels and same result
  * as mgs_pack_device with MGS_ALGO_AUTO, but the call allocates nothing: the
  * device-side control block and the chained-scan arrays of the one-sweep
  * kernels live in a static device array of the library (MGS_NOALLOC_SCAN_BYTES
@@ -334,7 +341,7 @@ int mgs_pack_streams_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next
  *
  * Limits (MGS_ERR_ARG with a message otherwise): layouts and rank counts the
  * one-sweep kernels take (at most 64 ranks, 63 with a local rank for other than
- * 16-byte records; fixed widths up to 79 bytes or variable width), and
+ * 16-byte records; fixed widths up to 75 bytes or variable width), and
  * ceil(n / tile) * (8*columns + 16*ceil(columns/4)) <= MGS_NOALLOC_SCAN_BYTES
  * with columns = nranks (+1 with a local rank, except 16-byte records) and
  * tile = 3584 records of 16 bytes, 1792 / 896 / 448 otherwise (the largest

@@ -91,6 +91,12 @@ class Exchange {
         (void) d_sendbuf; (void) scount; (void) sdispl; (void) d_recvbuf; (void) rcount; (void) rdispl;
         return false;
     }
+    // Does alltoallv_device move device memory?  Asked before anything is allocated for it:
+    // a transport that answers false (the default, and what an MPI library that is not
+    // GPU-aware answers) never sees alltoallv_device called, and the shuffler allocates no
+    // receive image on the device and no page-locked mirror of it.  A transport that
+    // overrides alltoallv_device overrides this too.
+    virtual bool moves_device_memory() const { return false; }
     // Non-blocking forms for NBGpuShuffler (MPI_Ialltoall / MPI_Ialltoallv /
     // MPI_Test / MPI_Wait; the counts and the payloads travel on two separate
     // communicators in the reference, src/nbcollectiveshuffler.h:68-69).  A
@@ -433,9 +439,11 @@ class GpuShuffler : public Writable<KeyType, ValType> {
         recv_bytes += (uint64_t) recvcount;
         // the payload: between the device images when the transport can, else through host memory
         void *d_recv = NULL;
-        if (mgs_stager_recv_image_device(stager, &d_recv) != MGS_OK) fail(mgs_stager_last_error(stager));
-        if (comm->alltoallv_device(d_image, send_count.data(), d_s_displs.data(), d_recv, recv_count.data(),
-                                   d_r_displs.data())) {
+        if (comm->moves_device_memory() && mgs_stager_recv_image_device(stager, &d_recv) != MGS_OK)
+            fail(mgs_stager_last_error(stager));
+        if (d_recv != NULL
+            && comm->alltoallv_device(d_image, send_count.data(), d_s_displs.data(), d_recv, recv_count.data(),
+                                      d_r_displs.data())) {
             device_exchanges += 1;
             const void *host = NULL;
             const uint32_t *off = NULL;

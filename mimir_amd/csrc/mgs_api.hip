@@ -662,13 +662,14 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         return MGS_ERR_ARG;
     }
     if (noalloc && algo == MGS_ALGO_GENERIC) {
-        h->err = "mgs_pack_device_noalloc: this layout / rank count needs the generic kernels, whose buffers "
-                 "are allocated per handle (at most 64 ranks, fixed widths up to 79 bytes or variable width)";
+        h->err = fmt("mgs_pack_device_noalloc: this layout / rank count needs the generic kernels, whose buffers "
+                     "are allocated per handle (the call takes at most 64 ranks, fixed widths up to %d bytes or "
+                     "variable width)", (OD_SB - OD_SLACK) / 64);
         return MGS_ERR_ARG;
     }
     if (algo == MGS_ALGO_ONESWEEPV && !ov_ok) {
-        h->err = "mgs_pack_device: ONESWEEPV needs nranks (+1 with a local rank) <= 64 and, for fixed "
-                 "widths, records of at most 79 bytes";
+        h->err = fmt("mgs_pack_device: ONESWEEPV needs nranks (+1 with a local rank) <= 64 and, for fixed "
+                     "widths, records of at most %d bytes", image_kernel ? (OV_IN_BYTES - 15) / kOvLanes : (OD_SB - OD_SLACK) / 64);
         return MGS_ERR_ARG;
     }
     if (algo == MGS_ALGO_ONESWEEP16 && !os_ok) {
@@ -1054,6 +1055,12 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
         h->err = "mgs_pack_result: no pack call in flight";
         return MGS_ERR_STATE;
     }
+    if (!rounds_caller && !h->pending_empty && (h->pending_rounds > 1 || h->pending_streams)) {
+        // the call stays in flight: its own result call can still fetch it
+        h->err = "mgs_pack_result: the call in flight packs several rounds (use mgs_pack_rounds_result / "
+                 "mgs_pack_streams_result)";
+        return MGS_ERR_STATE;
+    }
     h->pending = false;
     const int P = h->desc.nranks;
     memset(out, 0, sizeof(*out));
@@ -1067,6 +1074,7 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
     h->ev_valid = true;
     if (h->pending_osv && h->h_ctrl->head.fallback != 0) {
         // records too long for the one-sweep kernel's LDS staging: it did nothing
+        h->ov_shrink++; // the next call tries a smaller tile (and, when none is left, no one-sweep kernel at all)
         if (h->pending_noalloc) {
             h->err = "mgs_pack_device_noalloc: a wave's records do not fit the kernel's LDS staging buffer "
                      "(records too long); use mgs_pack_device";
@@ -1076,7 +1084,6 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
             h->err = "records too long for the one-sweep kernel's LDS staging: pack this batch round by round";
             return MGS_ERR_RECORD_SIZE;
         }
-        h->ov_shrink++; // the next call tries a smaller tile
         // the generic kernels redo the call (same stream, same arguments)
         int64_t init[MGS_MAX_RANKS];
         memcpy(init, h->pending_init, sizeof(init));
@@ -1109,11 +1116,6 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
         out->local_records = tab[3];
         out->local_bytes = (int64_t) tab[4];
         for (int b = 0; b < P; b++) out->send_offset[b] = (int64_t) tab[OS_RTAB_HEAD + 3 * R + b];
-        if ((R != 1 || h->pending_streams) && !rounds_caller) {
-            h->err = "mgs_pack_result: the call in flight packs several rounds (use mgs_pack_rounds_result / "
-                     "mgs_pack_streams_result)";
-            return MGS_ERR_STATE;
-        }
     }
     else {
         *out = h->h_ctrl->result;
@@ -1157,6 +1159,10 @@ static int rounds_in_kernel(const mgs_handle *h, const void *d_records, void *d_
     for (int b = 0; b < D.nranks && os16 && init_offset; b++) os16 = (init_offset[b] % 16) == 0;
     if (os16) return MGS_ALGO_ONESWEEP16;
     if (algo == MGS_ALGO_ONESWEEP16) return 0;
+    // A handle whose last one-sweep call met records too long for the staging buffer packs
+    // round by round (the generic kernels measure the record length call by call) until that
+    // length says that the smallest tile fits again.
+    if (h->fixed_len == 0 && h->ov_shrink > 0 && od_pick_k(1.25 * h->ov_bytes_per_record) == 0) return 0;
     // (a one-round call of the byte-granular layouts runs the LDS-image kernel through mgs_pack_device)
     const bool osd = (algo == MGS_ALGO_AUTO || algo == MGS_ALGO_ONESWEEPV) && !osv_image_kernel(h, max_rounds)
                      && D.nranks + (D.rank >= 0 ? 1 : 0) <= OS_MAXP

@@ -557,16 +557,11 @@ int mgs_stager_recv_image_device(mgs_stager *s, void **d_recv)
         int prev = -1;
         (void) hipGetDevice(&prev);
         const size_t image = (size_t) s->desc.nranks * (size_t) s->desc.buf_size;
-        // shortest record of the layout: the offsets table holds one entry per record
-        const mgs_layout &l = s->desc.layout;
-        const int fl = fixed_len(l);
-        const size_t minlen = fl > 0 ? (size_t) fl : 1 + (l.val_kind == MGS_VAL_FIXED ? (size_t) l.val_bytes : 0);
-        s->roff_cap = image / minlen + 2;
+        // (the table of record offsets is sized by what an exchange actually delivers, in
+        // mgs_stager_recv_to_host)
         hipError_t e = hipSetDevice(s->desc.device);
         if (e == hipSuccess) e = hipMalloc(&s->d_recv, image);
-        if (e == hipSuccess) e = hipMalloc(&s->d_roff, s->roff_cap * sizeof(uint32_t));
         if (e == hipSuccess) e = hipHostMalloc(&s->h_recv, image, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc(&s->h_roff, s->roff_cap * sizeof(uint32_t), hipHostMallocDefault);
         if (prev >= 0) (void) hipSetDevice(prev);
         if (e != hipSuccess) {
             s->err = sfmt("mgs_stager_recv_image_device: %s", hipGetErrorString(e));
@@ -607,6 +602,22 @@ int mgs_stager_recv_to_host(mgs_stager *s, int64_t nbytes, const void **host_rec
     STG_HIP(s, hipSetDevice(s->desc.device));
     STG_HIP(s, hipMemcpyAsync(s->h_recv, s->d_recv, (size_t) nbytes, hipMemcpyDeviceToHost, s->stream));
     if (device_parse) {
+        // one offset per record: the bytes received over the layout's shortest record
+        const int fl = fixed_len(l);
+        const size_t minlen = fl > 0 ? (size_t) fl : 1 + (l.val_kind == MGS_VAL_FIXED ? (size_t) l.val_bytes : 0);
+        const uint64_t need = (uint64_t) nbytes / minlen + 2;
+        if (need > s->roff_cap) {
+            STG_HIP(s, hipStreamSynchronize(s->stream)); // (nothing of the old tables is in flight after this)
+            if (s->d_roff) STG_HIP(s, hipFree(s->d_roff));
+            if (s->h_roff) STG_HIP(s, hipHostFree(s->h_roff));
+            s->d_roff = nullptr;
+            s->h_roff = nullptr;
+            s->roff_cap = 0;
+            const uint64_t cap = need + need / 4;
+            STG_HIP(s, hipMalloc(&s->d_roff, cap * sizeof(uint32_t)));
+            STG_HIP(s, hipHostMalloc(&s->h_roff, cap * sizeof(uint32_t), hipHostMallocDefault));
+            s->roff_cap = cap;
+        }
         uint64_t n = 0;
         int ncuts = 0;
         mgs_page_cut cut;

@@ -96,11 +96,16 @@ class ThreadExchange : public Exchange {
     }
     // Device memory: every rank pulls its partitions out of the other ranks' device images
     // (the ranks of this driver share one GPU; between GPUs the same copies are peer copies).
+    static bool device_exchange_on()
+    {
+        static const bool on = getenv("MGS_SHIM_DEVICE_EXCHANGE") && atoi(getenv("MGS_SHIM_DEVICE_EXCHANGE")) != 0;
+        return on;
+    }
+    bool moves_device_memory() const { return device_exchange_on(); }
     bool alltoallv_device(const void *d_sendbuf, const int *scount, const int64_t *sdispl, void *d_recvbuf,
                           const int *rcount, const int64_t *rdispl)
     {
-        static const bool on = getenv("MGS_SHIM_DEVICE_EXCHANGE") && atoi(getenv("MGS_SHIM_DEVICE_EXCHANGE")) != 0;
-        if (!on) return false;
+        if (!device_exchange_on()) return false;
         s->d_send[(size_t) r] = d_sendbuf;
         s->scount[(size_t) r] = scount;
         s->d_sdispl[(size_t) r] = sdispl;

@@ -22,6 +22,15 @@ def test_gpu_streams_shuffler_matches_reference_simulation(oracle, P, kind):
     run_case(oracle, P, kind, comm=16384, use_gpu="streams")
 
 
+def test_gpu_streams_shuffler_takes_long_records(oracle):
+    """Words of about a hundred bytes: the one-sweep kernels refuse the streams-layout call
+    (a tile's records do not fit their LDS image) and the shuffler packs the batch round by
+    round with the kernels that take any record up to a partition's size, as the reference
+    does -- same sinks, order and counters."""
+    counts = [900, 0, 1400]
+    run_case(oracle, 3, "longwords", comm=49152, use_gpu="streams", counts=counts)
+
+
 def test_gpu_shuffle_default_geometry(oracle):
     """The reference's default 64 MiB buffer: buf_size 32 MiB at P = 2."""
     # about 4.5 MiB of non-local records per rank against 32 MiB partitions:

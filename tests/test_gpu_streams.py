@@ -323,6 +323,16 @@ def test_streams_empty_call_and_wrong_result_call(oracle):
     assert e.value.status == capi.ERR_STATE
     got = pk.streams_result()
     assert got.next == n and got.n_rounds > 1
+    # ... and a rounds call asked for its result through the one-round call stays in flight:
+    # the rounds result call still fetches it
+    images = torch.empty(64 * P * 1600, dtype=torch.uint8, device="cuda:0")
+    pk.pack_rounds_async(d, n, images, P * 1600, 64, local_out=local)
+    with pytest.raises(capi.MgsError) as e:
+        pk.result()
+    assert e.value.status == capi.ERR_STATE
+    got2 = pk.rounds_result()
+    assert got2.next == n and got2.n_rounds == got.n_rounds
+    assert got2.round_send_offset.tolist() == got.round_send_offset.tolist()
     pk.close()
 
 

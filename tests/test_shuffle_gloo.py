@@ -32,6 +32,10 @@ def make_stream(kind, rank, n):
     elif kind == "words":
         blob, offs, lay = datagen.word_records(n, n_unique=400, alpha=1.0, len_mean=6,
                                                len_sd=1.5, seed=7 + rank)
+    elif kind == "longwords":
+        # words of 100 bytes and more among short ones: a tile of them exceeds the one-sweep
+        # kernels' LDS image, a record still fits a partition
+        blob, offs, lay = datagen.word_records(n, n_unique=300, alpha=0.7, len_mean=110, len_sd=30, seed=17 + rank)
     elif kind == "join":
         blob, offs, lay = datagen.join_records(n, n_unique=300, alpha=0.8, len_mean=5,
                                                len_sd=1, seed=9 + rank)

@@ -95,3 +95,27 @@ def test_noalloc_rejects_what_it_cannot_hold():
         pk.pack_noalloc(rec, 1000, image)
     assert e.value.status == capi.ERR_ARG
     pk.close()
+
+
+@pytest.mark.parametrize("width", [75, 76, 79])
+def test_noalloc_fixed_width_limit(width):
+    """Fixed widths up to 75 bytes fit the call's kernel (64 records of a wave in its LDS
+    slice); wider records are refused with the limit in the message."""
+    import torch
+    from mimir_amd.packer import DevicePacker
+    n, P, rank = 20_000, 6, 1
+    rng = np.random.default_rng(width)
+    blob = rng.integers(0, 256, size=n * width, dtype=np.uint8)
+    lay = capi.Layout.make(capi.KEY_FIXED, 8, capi.VAL_FIXED, width - 8)
+    buf = (n * width // P * 2) // 16 * 16
+    pk = DevicePacker(lay, P, rank, buf, max_records=n)
+    if width <= 75:
+        r = _both(pk, blob, None, n, P, rank, buf)
+        assert r.next == n
+    else:
+        image = torch.empty(P * buf, dtype=torch.uint8, device="cuda:0")
+        local = torch.empty(n * width, dtype=torch.uint8, device="cuda:0")
+        with pytest.raises(capi.MgsError) as e:
+            pk.pack_noalloc(torch.from_numpy(blob).cuda(), n, image, local_out=local)
+        assert e.value.status == capi.ERR_ARG and "75 bytes" in str(e.value)
+    pk.close()
