@@ -303,8 +303,11 @@ int mgs_pack_rounds_result(mgs_handle *h, mgs_rounds *out, uint64_t *round_next,
  * what the one-sweep kernels take (at most 64 ranks, 63 with a local rank
  * unless records are 16 bytes; fixed widths up to 79 bytes or variable width;
  * 16-byte records need 16-byte aligned buffers, fills and stream_cap);
- * MGS_ERR_ARG otherwise, MGS_ERR_RECORD_SIZE for variable-width records too
- * long for the kernel's LDS staging (use mgs_pack_rounds_device there). */
+ * MGS_ERR_ARG otherwise.  Variable-width records too long for the kernel's LDS
+ * staging: the blocking call packs the batch round by round with the generic
+ * kernels and appends each round's partitions to the streams (it then begins a
+ * round only while every stream has room for a whole partition); the _async /
+ * _result pair returns MGS_ERR_RECORD_SIZE. */
 int mgs_pack_streams_device(mgs_handle *h, const void *d_records,
                             const uint32_t *d_rec_off, uint64_t n_end,
                             uint64_t start, const int64_t *stream_fill,
@@ -565,6 +568,15 @@ int mgs_stager_send_image_to(mgs_stager *s, void *host_dst,
                              const int64_t **send_offset);
 void *mgs_host_alloc(size_t bytes);
 void mgs_host_free(void *p);
+/* Device memory on GPU `device`, and a blocking copy from it into host memory
+ * (page-locked or not), for host code that keeps device buffers of its own
+ * without being built against HIP: the destination streams of a whole map in
+ * the shuffler for device-resident batches (mimir_gpu::StreamsGpuShuffler; the
+ * reference's buffers come from mem_aligned_malloc, src/collectiveshuffler.h:
+ * 95-98).  NULL / MGS_ERR_HIP on failure. */
+void *mgs_device_alloc(int device, size_t bytes);
+void mgs_device_free(int device, void *p);
+int mgs_copy_to_host(int device, void *host_dst, const void *d_src, size_t bytes);
 int mgs_stager_send_image_device(mgs_stager *s, void **d_image,
                                  const int64_t **send_offset);
 int mgs_stager_round_done(mgs_stager *s);

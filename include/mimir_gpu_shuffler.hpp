@@ -20,6 +20,7 @@
 #ifndef MIMIR_GPU_SHUFFLER_HPP
 #define MIMIR_GPU_SHUFFLER_HPP
 
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -852,6 +853,444 @@ class NBGpuShuffler : public GpuShuffler<KeyType, ValType> {
     int cur_idx;
     uint64_t a2a_token, a2av_token;
     int pending_msg;
+};
+
+// ---- the shuffler for device-resident batches ------------------------------------
+// CollectiveShuffler for a map whose emitted records already lie in device memory in wire
+// form (what mgs_tokenize_device leaves, a generator kernel's output, a container kept in
+// HBM): no record crosses the per-record write(key*, val*) boundary on the way in.
+//
+//     open();  write_device_records(d_blob, n, d_rec_off)  any number of times, in emit
+//     order;  close()
+//
+// Every batch is packed with mgs_pack_streams_device into one stream per destination,
+// going on where the batch before stopped, so the rounds are those CollectiveShuffler::write
+// would cut over the whole sequence of records (src/collectiveshuffler.h:131-166).  Nothing
+// travels before close(): the whole map's partitions stay in HBM (MIMIR_GPU_STREAM_SIZE
+// bytes per destination, 1 GiB unless set).  close() tells every rank the send counts of all
+// rounds at once (the counts all-to-all of :606-607, for every round), then moves the rounds
+// a window at a time -- as many consecutive rounds as MIMIR_GPU_WINDOW_SIZE (256 MiB) holds
+// -- with one all-to-all-v per window whose displacements point into the streams: between
+// device buffers when the transport moves device memory (Exchange::alltoallv_device, 64-bit
+// displacements), else through a host mirror of the window.  `out` sees what the
+// reference's `out` sees, in its order: the local records of round k (emitted during it,
+// :135-141), then round k's receive image source by source (:563-585), for k = 0, 1, ...
+// On the device path the record boundaries come from mgs_unpack_device.  shuffle_times,
+// kvcount and the byte counters are those of the reference's exchanges.
+//
+// write(key*, val*) is not served: a map that emits pair by pair uses GpuShuffler.
+template <typename KeyType, typename ValType>
+class StreamsGpuShuffler : public Writable<KeyType, ValType> {
+  public:
+    // CollectiveShuffler's parameter list (src/collectiveshuffler.h:25-31) with the
+    // communicator replaced by an Exchange, then: bytes per destination stream (0: the
+    // environment or 1 GiB), most records one pack call takes, most rounds one call reports.
+    StreamsGpuShuffler(Exchange *comm, Writable<KeyType, ValType> *out,
+                       int (*user_hash)(KeyType *key, ValType *val, int npartition), int keycount,
+                       int valcount, bool split_hint = false, void *h = NULL, int64_t comm_buf_size = 0,
+                       int device = 0, int64_t stream_bytes = 0, uint64_t max_records = 0,
+                       uint32_t max_rounds = 4096)
+        : comm(comm), out(out), keycount(keycount), valcount(valcount), device(device), max_rounds(max_rounds)
+    {
+        (void) split_hint;
+        (void) h;
+        shuffle_rank = comm->rank();
+        shuffle_size = comm->size();
+        handle = NULL;
+        d_streams = d_local = NULL;
+        if (out == NULL) fail("Output shuffler cannot be NULL!\n"); // src/baseshuffler.h:35
+        if (user_hash != NULL)
+            fail("StreamsGpuShuffler: a user hash callback runs on the host per record; "
+                 "use CollectiveShuffler for this map\n");
+        this->comm_buf_size = comm_buf_size > 0 ? comm_buf_size : env_size("MIMIR_COMM_SIZE", 64 << 20);
+        int unit = 0, tlb = 0;
+        if (mgs_geometry(this->comm_buf_size, shuffle_size, &buf_size, &unit, &tlb) != MGS_OK)
+            fail("The communication buffer is too small!\n"); // src/collectiveshuffler.h:38-41
+        if (tlb > 0) fail("StreamsGpuShuffler: MIMIR_COMM_SIZE above 1 GiB is not supported (use GpuShuffler)\n");
+        if (stream_bytes <= 0) stream_bytes = env_size("MIMIR_GPU_STREAM_SIZE", (int64_t) 1 << 30);
+        stream_cap = stream_bytes / 16 * 16;
+        if (stream_cap < buf_size) fail("StreamsGpuShuffler: a destination stream must hold one partition\n");
+        this->max_records = max_records ? max_records : ((uint64_t) 1 << 26);
+        window_bytes = env_size("MIMIR_GPU_WINDOW_SIZE", 256 << 20);
+        if (window_bytes > 0x7fffffffLL) window_bytes = 0x7fffffffLL; // counts and host displacements are ints
+        if (this->max_rounds < 2) this->max_rounds = 2;
+        reset_counters();
+    }
+
+    virtual ~StreamsGpuShuffler() { release(); }
+
+    virtual int open()
+    {
+        mgs_desc d;
+        shuffler_desc(d);
+        if (mgs_create(&d, &handle) != MGS_OK) fail(mgs_last_error(NULL));
+        const size_t P = (size_t) shuffle_size;
+        d_streams = static_cast<char *>(mgs_device_alloc(device, P * (size_t) stream_cap));
+        d_local = static_cast<char *>(mgs_device_alloc(device, (size_t) stream_cap));
+        if (d_streams == NULL || d_local == NULL)
+            fail("StreamsGpuShuffler: no device memory for the destination streams (MIMIR_GPU_STREAM_SIZE)\n");
+        reset_counters();
+        t_next.resize(max_rounds);
+        t_lrec.resize(max_rounds);
+        t_lbytes.resize(max_rounds);
+        t_so.resize((size_t) max_rounds * P);
+        t_base.resize((size_t) max_rounds * P);
+        return true;
+    }
+
+    // The records [0, n) of a device-resident batch in wire form, emit order; d_rec_off (n + 1
+    // offsets on the device) for variable-width layouts, NULL for fixed widths.  Blocking.
+    int write_device_records(const void *d_blob, uint64_t n, const uint32_t *d_rec_off = NULL)
+    {
+        if (handle == NULL) fail("StreamsGpuShuffler: write_device_records before open()\n");
+        const size_t P = (size_t) shuffle_size;
+        uint64_t start = 0;
+        while (start < n) {
+            mgs_rounds r;
+            const bool going_on = !r_so.empty();
+            const int rc = mgs_pack_streams_device(handle, d_blob, d_rec_off, n, start, going_on ? fill.data() : NULL,
+                                                   going_on ? open_base.data() : NULL, d_streams, stream_cap, max_rounds,
+                                                   d_local + lused, stream_cap - lused, NULL, NULL, &r, t_next.data(),
+                                                   t_so.data(), t_base.data(), t_lrec.data(), t_lbytes.data());
+            if (rc != MGS_OK) fail(mgs_last_error(handle));
+            const uint64_t consumed = r.next - start;
+            if (consumed == 0 && r.n_rounds >= max_rounds) fail("StreamsGpuShuffler: max_rounds too small for this batch\n");
+            if (r.next < n && r.n_rounds < max_rounds && consumed < this->max_records)
+                fail("StreamsGpuShuffler: a destination stream is full (raise MIMIR_GPU_STREAM_SIZE)\n");
+            // the first round of this call is the open round of the call before going on
+            size_t first = 0;
+            if (going_on) {
+                const size_t last = r_lbytes.size() - 1;
+                for (size_t b = 0; b < P; b++) r_so[last * P + b] = t_so[b];
+                r_lbytes[last] += t_lbytes[0];
+                first = 1;
+            }
+            for (size_t k = first; k < r.n_rounds; k++) {
+                r_so.insert(r_so.end(), t_so.begin() + (ptrdiff_t)(k * P), t_so.begin() + (ptrdiff_t)((k + 1) * P));
+                r_base.insert(r_base.end(), t_base.begin() + (ptrdiff_t)(k * P), t_base.begin() + (ptrdiff_t)((k + 1) * P));
+                r_lbytes.push_back(t_lbytes[k]);
+            }
+            const size_t lastk = (size_t) r.n_rounds - 1;
+            open_base.assign(t_base.begin() + (ptrdiff_t)(lastk * P), t_base.begin() + (ptrdiff_t)((lastk + 1) * P));
+            fill.resize(P);
+            for (size_t b = 0; b < P; b++) fill[b] = (int) b == shuffle_rank ? 0 : open_base[b] + t_so[lastk * P + b];
+            lused += r.local_bytes;
+            kvcount += r.packed_records;
+            start = r.next;
+        }
+        return true;
+    }
+
+    virtual int write(KeyType *, ValType *)
+    {
+        fail("StreamsGpuShuffler: write(key, val) is not served; emit device batches with write_device_records, "
+             "or use GpuShuffler\n");
+        return false;
+    }
+
+    virtual void close()
+    {
+        if (handle != NULL) exchange_all();
+        release();
+    }
+
+    virtual void make_progress(bool issue_new = false) { (void) issue_new; } // nothing travels before close()
+    virtual int seek(DB_POS) { return false; }
+    virtual uint64_t get_record_count() { return kvcount; } // src/baseshuffler.h:265
+
+    int get_shuffle_times() const { return shuffle_times; }
+    uint64_t get_send_bytes() const { return send_bytes; } // as GpuShuffler's
+    uint64_t get_recv_bytes() const { return recv_bytes; }
+    int get_device_exchanges() const { return device_exchanges; } // all-to-all-v calls between device buffers
+
+  protected:
+    virtual void begin_source(int src) { (void) src; }
+
+    void shuffler_desc(mgs_desc &d) const
+    {
+        memset(&d, 0, sizeof(d));
+        d.nranks = shuffle_size;
+        d.rank = shuffle_rank;
+        d.layout.key_kind = wire<KeyType>::kind;
+        d.layout.key_bytes = (wire<KeyType>::kind == MGS_KEY_FIXED) ? wire<KeyType>::size(NULL, keycount) : 0;
+        d.layout.key_count = keycount;
+        d.layout.val_kind = wire<ValType>::is_void ? MGS_VAL_VOID
+                            : (wire<ValType>::kind == MGS_KEY_CSTR ? MGS_VAL_CSTR : MGS_VAL_FIXED);
+        d.layout.val_bytes = (d.layout.val_kind == MGS_VAL_FIXED) ? wire<ValType>::size(NULL, valcount) : 0;
+        d.layout.val_count = valcount;
+        d.buf_size = buf_size;
+        d.device = device;
+        d.max_records = max_records;
+    }
+
+    // Does mgs_unpack_device take this layout?  (fixed widths; one string key with a fixed value of
+    // at most 62 bytes or none)  Shortest record of the layout in *minlen.
+    bool device_parse(size_t *minlen) const
+    {
+        mgs_desc d;
+        shuffler_desc(d);
+        const mgs_layout &l = d.layout;
+        if (l.key_kind == MGS_KEY_FIXED && l.val_kind != MGS_VAL_CSTR) {
+            *minlen = (size_t) l.key_bytes + (size_t) l.val_bytes;
+            return *minlen > 0;
+        }
+        *minlen = 1 + (l.val_kind == MGS_VAL_FIXED ? (size_t) l.val_bytes : 0);
+        return l.key_kind == MGS_KEY_CSTR && l.key_count <= 1
+               && (l.val_kind == MGS_VAL_VOID || (l.val_kind == MGS_VAL_FIXED && l.val_bytes <= 62));
+    }
+
+    // Every exchange of the map (src/collectiveshuffler.h:587-674, once per round there).
+    void exchange_all()
+    {
+        const size_t P = (size_t) shuffle_size, me = (size_t) shuffle_rank;
+        if (r_lbytes.empty()) { // nothing was written: one empty round, as wait() makes (:531-534)
+            r_so.assign(P, 0);
+            r_base.assign(P, 0);
+            r_lbytes.assign(1, 0);
+        }
+        const size_t r_mine = r_lbytes.size();
+        // how many rounds every rank has
+        std::vector<int> a(P, (int) r_mine), r_of(P, 0);
+        comm->alltoall_int(a.data(), r_of.data());
+        size_t R = 0, tab_words = 0;
+        for (size_t s = 0; s < P; s++) {
+            if ((size_t) r_of[s] > R) R = (size_t) r_of[s];
+            tab_words += (size_t) r_of[s];
+        }
+        // the send counts of all rounds: to destination d the column d of this rank's table
+        std::vector<int> tab_s(P * r_mine), tab_r(tab_words ? tab_words : 1);
+        std::vector<int> sc(P), sd(P), rcv(P), rd(P);
+        size_t pos = 0;
+        for (size_t d = 0; d < P; d++) {
+            for (size_t k = 0; k < r_mine; k++) {
+                tab_s[d * r_mine + k] = (int) r_so[k * P + d];
+                send_bytes += (uint64_t) r_so[k * P + d];
+            }
+            sc[d] = (int) (r_mine * sizeof(int));
+            sd[d] = (int) (d * r_mine * sizeof(int));
+            rcv[d] = (int) ((size_t) r_of[d] * sizeof(int));
+            rd[d] = (int) (pos * sizeof(int));
+            pos += (size_t) r_of[d];
+        }
+        comm->alltoallv_bytes(reinterpret_cast<const char *>(tab_s.data()), sc.data(), sd.data(),
+                              reinterpret_cast<char *>(tab_r.data()), rcv.data(), rd.data());
+        std::vector<int64_t> rc(R * P, 0); // rc[k*P + s]: bytes of source s's round k for this rank
+        for (size_t s = 0; s < P; s++)
+            for (size_t k = 0; k < (size_t) r_of[s]; k++) {
+                rc[k * P + s] = tab_r[(size_t) rd[s] / sizeof(int) + k];
+                recv_bytes += (uint64_t) rc[k * P + s];
+            }
+        // the local records, all of them (they never leave this rank)
+        std::vector<char> h_local((size_t) lused ? (size_t) lused : 1);
+        if (mgs_copy_to_host(device, h_local.data(), d_local, (size_t) lused) != MGS_OK)
+            fail("StreamsGpuShuffler: copy of the local records failed\n");
+        // windows of W consecutive rounds
+        const int64_t round_bytes = buf_size * (int64_t) P;
+        const size_t W = (size_t) (window_bytes / round_bytes > 0 ? window_bytes / round_bytes : 1);
+        int64_t win_max = 0;
+        for (size_t k0 = 0; k0 < R; k0 += W) {
+            int64_t tot_r = 0, tot_s = 0;
+            for (size_t k = k0; k < R && k < k0 + W; k++)
+                for (size_t b = 0; b < P; b++) {
+                    tot_r += rc[k * P + b];
+                    if (k < r_mine) tot_s += r_so[k * P + b];
+                }
+            if (tot_r > win_max) win_max = tot_r;
+            if (tot_s > win_max) win_max = tot_s;
+        }
+        const bool on_device = comm->moves_device_memory();
+        size_t minlen = 1;
+        const bool parse = on_device && device_parse(&minlen);
+        const size_t win_cap = (size_t) (win_max > 0 ? win_max : 1);
+        char *h_recv = static_cast<char *>(mgs_host_alloc(win_cap));
+        char *h_send = on_device ? NULL : static_cast<char *>(mgs_host_alloc(win_cap));
+        char *d_recv = on_device ? static_cast<char *>(mgs_device_alloc(device, win_cap)) : NULL;
+        const uint64_t off_cap = parse ? (uint64_t) win_cap / minlen + 2 : 0;
+        uint32_t *d_off = parse ? static_cast<uint32_t *>(mgs_device_alloc(device, (size_t) off_cap * 4)) : NULL;
+        uint32_t *h_off = parse ? static_cast<uint32_t *>(mgs_host_alloc((size_t) off_cap * 4)) : NULL;
+        if (h_recv == NULL || (!on_device && h_send == NULL) || (on_device && d_recv == NULL)
+            || (parse && (d_off == NULL || h_off == NULL)))
+            fail("StreamsGpuShuffler: no memory for an exchange window (MIMIR_GPU_WINDOW_SIZE)\n");
+        std::vector<int64_t> sd64(P), rd64(P);
+        std::vector<uint64_t> cursor(P, 0);
+        int64_t lpos = 0;
+        for (size_t k0 = 0; k0 < R; k0 += W) {
+            const size_t k1 = k0 + W < R ? k0 + W : R;
+            int64_t tot_r = 0, tot_s = 0;
+            for (size_t b = 0; b < P; b++) {
+                int64_t s_b = 0, r_b = 0;
+                for (size_t k = k0; k < k1; k++) {
+                    r_b += rc[k * P + b];
+                    if (k < r_mine) s_b += r_so[k * P + b];
+                }
+                sc[b] = (int) s_b;
+                rcv[b] = (int) r_b;
+                sd[b] = (int) tot_s;
+                rd[b] = (int) tot_r;
+                rd64[b] = tot_r;
+                // the rounds of a window lie back to back in a destination's stream
+                sd64[b] = (int64_t) b * stream_cap + (k0 < r_mine ? r_base[k0 * P + b] : 0);
+                tot_s += s_b;
+                tot_r += r_b;
+            }
+            uint64_t nrec = 0;
+            if (on_device) {
+                if (!comm->alltoallv_device(d_streams, sc.data(), sd64.data(), d_recv, rcv.data(), rd64.data()))
+                    fail("StreamsGpuShuffler: the transport said it moves device memory, then moved nothing\n");
+                device_exchanges += 1;
+                if (parse && tot_r > 0) {
+                    mgs_page_cut cut;
+                    int ncuts = 0;
+                    if (mgs_unpack_device(handle, d_recv, (uint64_t) tot_r, d_off, off_cap, (int64_t) 1 << 40, 0, &nrec,
+                                          &cut, 1, &ncuts, NULL) != MGS_OK)
+                        fail(mgs_last_error(handle));
+                    if (mgs_copy_to_host(device, h_off, d_off, (size_t) (nrec + 1) * 4) != MGS_OK)
+                        fail("StreamsGpuShuffler: copy of the record offsets failed\n");
+                }
+                if (mgs_copy_to_host(device, h_recv, d_recv, (size_t) tot_r) != MGS_OK)
+                    fail("StreamsGpuShuffler: copy of a receive window failed\n");
+            }
+            else {
+                for (size_t b = 0; b < P; b++)
+                    if (mgs_copy_to_host(device, h_send + sd[b], d_streams + sd64[b], (size_t) sc[b]) != MGS_OK)
+                        fail("StreamsGpuShuffler: copy of a send window failed\n");
+                comm->alltoallv_bytes(h_send, sc.data(), sd.data(), h_recv, rcv.data(), rd.data());
+            }
+            // where every source's records begin in the offsets table
+            if (parse && tot_r > 0)
+                for (size_t b = 0; b < P; b++) {
+                    uint64_t lo = 0, hi = nrec;
+                    while (lo < hi) {
+                        const uint64_t mid = (lo + hi) / 2;
+                        if ((int64_t) h_off[mid] < rd64[b]) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    cursor[b] = lo;
+                }
+            std::vector<int64_t> at(rd64); // per source: the next byte of its slice to hand over
+            for (size_t k = k0; k < k1; k++) {
+                if (k < r_mine && r_lbytes[k] > 0) { // out->write at emit time, :135-141
+                    begin_source(shuffle_rank);
+                    deliver(h_local.data() + lpos, r_lbytes[k]);
+                    lpos += r_lbytes[k];
+                }
+                for (size_t b = 0; b < P; b++) { // save_data, :563-585
+                    const int64_t len = rc[k * P + b];
+                    if (b == me || len <= 0) continue;
+                    begin_source((int) b);
+                    const int64_t end = at[b] + len;
+                    if (parse) { // the record boundaries came from the device: no length is measured here
+                        uint64_t &c = cursor[b];
+                        while (c < nrec && (int64_t) h_off[c] < end) {
+                            deliver_one(h_recv + h_off[c], (int) (h_off[c + 1] - h_off[c]));
+                            c++;
+                        }
+                    }
+                    else
+                        deliver(h_recv + at[b], len);
+                    at[b] = end;
+                }
+            }
+        }
+        shuffle_times = (int) R;
+        mgs_host_free(h_recv);
+        mgs_host_free(h_send);
+        mgs_host_free(h_off);
+        mgs_device_free(device, d_recv);
+        mgs_device_free(device, d_off);
+    }
+
+    // kv_from_bytes over back-to-back records (src/serializer.h:376-403)
+    void deliver(char *buf, int64_t nbytes)
+    {
+        int64_t pos = 0;
+        while (pos < nbytes) {
+            KeyType *key = NULL;
+            pos += wire<KeyType>::from(buf + pos, keycount, key, key_ptrs);
+            ValType *val = NULL;
+            pos += val_from(buf + pos, val, std::integral_constant<bool, wire<ValType>::is_void>());
+            out->write(key, val);
+        }
+    }
+    // one record whose extent is known: the key starts it, the value ends it
+    void deliver_one(char *rec, int len)
+    {
+        KeyType *key = NULL;
+        ValType *val = NULL;
+        const int vlen = wire<ValType>::is_void ? 0 : wire<ValType>::size(NULL, valcount);
+        wire<KeyType>::at(rec, key, key_ptrs);
+        val_at(rec + len - vlen, val, std::integral_constant<bool, wire<ValType>::is_void>());
+        out->write(key, val);
+    }
+    void val_at(char *, ValType *&val, std::true_type) { val = NULL; }
+    void val_at(char *buf, ValType *&val, std::false_type) { wire<ValType>::at(buf, val, val_ptrs); }
+    int val_from(char *, ValType *&val, std::true_type)
+    {
+        val = NULL;
+        return 0;
+    }
+    int val_from(char *buf, ValType *&val, std::false_type) { return wire<ValType>::from(buf, valcount, val, val_ptrs); }
+
+    void reset_counters()
+    {
+        shuffle_times = device_exchanges = 0;
+        kvcount = send_bytes = recv_bytes = 0;
+        lused = 0;
+        r_so.clear();
+        r_base.clear();
+        r_lbytes.clear();
+        fill.clear();
+        open_base.clear();
+    }
+
+    void release()
+    {
+        if (d_streams) mgs_device_free(device, d_streams);
+        if (d_local) mgs_device_free(device, d_local);
+        if (handle) mgs_destroy(handle);
+        d_streams = d_local = NULL;
+        handle = NULL;
+    }
+
+    void fail(const char *msg)
+    {
+        fprintf(stderr, "%d[%d] %s: %s", shuffle_rank, shuffle_size, "StreamsGpuShuffler", msg);
+        fflush(stderr);
+        comm->abort(1);
+        std::abort();
+    }
+
+    static int64_t env_size(const char *name, int64_t dflt)
+    {
+        const char *v = getenv(name);
+        if (!v || !*v) return dflt;
+        char *end = NULL;
+        double x = strtod(v, &end);
+        int64_t mul = 1;
+        if (end && (*end == 'k' || *end == 'K')) mul = 1024;
+        else if (end && (*end == 'm' || *end == 'M')) mul = 1024 * 1024;
+        else if (end && (*end == 'g' || *end == 'G')) mul = 1024LL * 1024 * 1024;
+        return (int64_t)(x * (double) mul);
+    }
+
+    Exchange *comm;
+    Writable<KeyType, ValType> *out;
+    int keycount, valcount, device;
+    uint32_t max_rounds;
+    uint64_t max_records;
+    int shuffle_rank, shuffle_size, shuffle_times, device_exchanges;
+    uint64_t kvcount, send_bytes, recv_bytes;
+    int64_t comm_buf_size, buf_size, stream_cap, window_bytes, lused;
+    mgs_handle *handle;
+    char *d_streams, *d_local;
+    // the rounds of the map so far: send counts and stream offsets [round][destination],
+    // bytes of local records per round; the open round's fill and base per destination
+    std::vector<int64_t> r_so, r_base, r_lbytes, fill, open_base;
+    // one call's result tables
+    std::vector<uint64_t> t_next, t_lrec;
+    std::vector<int64_t> t_so, t_base, t_lbytes;
+    typename ptr_store<KeyType>::type key_ptrs;
+    typename ptr_store<ValType>::type val_ptrs;
 };
 
 } // namespace mimir_gpu

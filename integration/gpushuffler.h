@@ -79,4 +79,27 @@ class GpuShuffler : public BaseShuffler<K, V> {
     MpiExchange ex; OutAdapter<K, V> adapter; mimir_gpu::GpuShuffler<K, V> impl;
 };
 
+// The same for a map that emits device-resident batches (wire-form records in HBM, e.g. what
+// mgs_tokenize_device leaves): the callback is handed this object as its Writable
+// (src/mimircontext.h:257) and reaches write_device_records through a dynamic_cast.
+template <typename K, typename V>
+class StreamsGpuShuffler : public BaseShuffler<K, V> {
+  public:
+    StreamsGpuShuffler(MPI_Comm comm, Writable<K, V> *out, int (*user_hash)(K *, V *, int),
+                       int keycount, int valcount, bool split_hint, HashBucket<> *h)
+        : BaseShuffler<K, V>(comm, out, user_hash, keycount, valcount, split_hint, h),
+          ex(comm), adapter(out),
+          impl(&ex, &adapter, user_hash, keycount, valcount, split_hint, h, COMM_BUF_SIZE, gpu_of_rank()) {}
+    virtual int open() { return impl.open(); }
+    virtual int write(K *k, V *v) { return impl.write(k, v); }   // refused: pair-by-pair maps use GpuShuffler
+    int write_device_records(const void *d_records, uint64_t n, const uint32_t *d_rec_off = NULL)
+    { return impl.write_device_records(d_records, n, d_rec_off); }
+    virtual void close() { impl.close(); }                        // every exchange of the map, then `out` is served
+    virtual void make_progress(bool issue_new = false) { impl.make_progress(issue_new); }
+    virtual uint64_t get_record_count() { return impl.get_record_count(); }
+  private:
+    static int gpu_of_rank() { const char *l = getenv("MPI_LOCALRANKID"); return l ? atoi(l) : 0; }
+    MpiExchange ex; OutAdapter<K, V> adapter; mimir_gpu::StreamsGpuShuffler<K, V> impl;
+};
+
 } // namespace MIMIR_NS

@@ -129,6 +129,9 @@ SYMBOLS = {
     "mgs_stager_send_image_to": (C.c_int, [_VP, _VP, _VP]),
     "mgs_host_alloc": (_VP, [C.c_size_t]),
     "mgs_host_free": (None, [_VP]),
+    "mgs_device_alloc": (_VP, [C.c_int, C.c_size_t]),
+    "mgs_device_free": (None, [C.c_int, _VP]),
+    "mgs_copy_to_host": (C.c_int, [C.c_int, _VP, _VP, C.c_size_t]),
     "mgs_stager_window": (C.c_int, [_VP, _VP]),
     "mgs_stager_commit": (C.c_int, [_VP, C.c_int64, C.c_uint64]),
     "mgs_stager_recv_image_device": (C.c_int, [_VP, C.POINTER(_VP)]),

@@ -129,6 +129,7 @@ struct mgs_handle {
     size_t rt_words = 0, rtab_words = 0;
     uint32_t pending_rounds = 0; // > 0: the call in flight leaves a result table for that many rounds
     bool pending_streams = false; // ... in the streams layout (rounds are views into destination streams)
+    uint8_t *d_round_image = nullptr; // streams layout packed round by round: the send image of one round
     uint8_t *d_unp = nullptr;   // receive-side scratch (chunk and piece tables, cuts, result)
     size_t unp_bytes = 0;
     uint8_t *d_grp = nullptr;   // reduce-side scratch (tables, sort buffers)
@@ -286,6 +287,7 @@ void mgs_destroy(mgs_handle *h)
         if (h->d_rt) (void) hipFree(h->d_rt);
         if (h->d_rtab) (void) hipFree(h->d_rtab);
         if (h->h_rtab) (void) hipHostFree(h->h_rtab);
+        if (h->d_round_image) (void) hipFree(h->d_round_image);
         if (h->d_unp) (void) hipFree(h->d_unp);
         if (h->d_grp) (void) hipFree(h->d_grp);
         if (h->h_unp) (void) hipHostFree(h->h_unp);
@@ -1312,6 +1314,88 @@ int mgs_pack_streams_device_async(mgs_handle *h, const void *d_records, const ui
     return rc;
 }
 
+// The streams layout for records the one-sweep kernels do not take (a tile's records longer
+// than their LDS image): one mgs_pack_device call per round with the generic kernels, which
+// take any record up to buf_size as CollectiveShuffler::write does
+// (src/collectiveshuffler.h:131-166), into a send image of the handle's own; what a call
+// added to a partition is appended to that destination's stream.  A round is only begun
+// when every stream has room for a whole partition.
+static int streams_round_by_round(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
+                                  uint64_t start, const int64_t *stream_fill, const int64_t *open_round_base,
+                                  void *d_streams, int64_t stream_cap, uint32_t max_rounds, void *d_local_out,
+                                  int64_t local_cap, uint8_t *d_dest_out, void *stream, mgs_rounds *out,
+                                  uint64_t *round_next, int64_t *round_send_offset, int64_t *round_base,
+                                  uint64_t *round_local_records, int64_t *round_local_bytes)
+{
+    const int P = h->desc.nranks, me = h->desc.rank;
+    const int64_t buf = h->desc.buf_size;
+    DeviceGuard g(h->desc.device);
+    if (!h->d_round_image) MGS_HIP(h, hipMalloc(&h->d_round_image, (size_t) P * (size_t) buf));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->own_stream;
+    int64_t fill[MGS_MAX_RANKS], base[MGS_MAX_RANKS], init[MGS_MAX_RANKS];
+    for (int b = 0; b < MGS_MAX_RANKS; b++) {
+        fill[b] = (stream_fill && b < P && b != me) ? stream_fill[b] : 0;
+        base[b] = (open_round_base && b < P && b != me) ? open_round_base[b] : fill[b];
+        init[b] = 0;
+    }
+    memset(out, 0, sizeof(*out));
+    out->next = start;
+    uint64_t cur = start, lrec_k = 0;
+    int64_t lused = 0, lbytes_k = 0;
+    uint32_t k = 0;
+    auto report = [&](uint32_t row) {
+        if (round_next) round_next[row] = cur;
+        if (round_local_records) round_local_records[row] = lrec_k;
+        if (round_local_bytes) round_local_bytes[row] = lbytes_k;
+        for (int b = 0; b < P; b++) {
+            if (round_send_offset) round_send_offset[(size_t) row * P + b] = b == me ? 0 : fill[b] - base[b];
+            if (round_base) round_base[(size_t) row * P + b] = base[b];
+        }
+        out->n_rounds = row + 1;
+    };
+    for (;;) {
+        bool room = true;
+        for (int b = 0; b < P; b++) room = room && (b == me || base[b] + buf <= stream_cap);
+        if (!room) { // a stream is full: the round stays open, the caller sees next < n_end
+            report(k);
+            return MGS_OK;
+        }
+        for (int b = 0; b < P; b++) init[b] = b == me ? 0 : fill[b] - base[b];
+        mgs_round r;
+        const int rc = mgs_pack_device(h, d_records, d_rec_off, n_end, cur, init, h->d_round_image,
+                                       d_local_out ? static_cast<uint8_t *>(d_local_out) + lused : nullptr,
+                                       local_cap - lused, d_dest_out ? d_dest_out + (cur - start) : nullptr,
+                                       MGS_ALGO_GENERIC, st, &r);
+        if (rc) return rc;
+        for (int b = 0; b < P; b++) {
+            const int64_t add = b == me ? 0 : r.send_offset[b] - init[b];
+            if (add <= 0) continue;
+            MGS_HIP(h, hipMemcpyAsync(static_cast<uint8_t *>(d_streams) + (size_t) b * (size_t) stream_cap + fill[b],
+                                      h->d_round_image + (size_t) b * (size_t) buf + init[b], (size_t) add,
+                                      hipMemcpyDeviceToDevice, st));
+            fill[b] += add;
+        }
+        const uint64_t consumed = r.next - cur;
+        cur = r.next;
+        lused += r.local_bytes;
+        lrec_k += r.local_records;
+        lbytes_k += r.local_bytes;
+        out->packed_records += r.packed_records;
+        out->local_records += r.local_records;
+        out->local_bytes += r.local_bytes;
+        out->next = cur;
+        if (cur < n_end && consumed == h->desc.max_records) continue; // same round, next stretch of records
+        report(k);
+        k++;
+        if (cur >= n_end || k == max_rounds) break;
+        for (int b = 0; b < P; b++) base[b] = fill[b]; // the record that did not fit opens the next round
+        lrec_k = 0;
+        lbytes_k = 0;
+    }
+    MGS_HIP(h, hipStreamSynchronize(st)); // the scratch image may be reused, the streams read, on return
+    return MGS_OK;
+}
+
 int mgs_pack_streams_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,
                             uint64_t start, const int64_t *stream_fill, const int64_t *open_round_base, void *d_streams,
                             int64_t stream_cap, uint32_t max_rounds, void *d_local_out, int64_t local_cap,
@@ -1320,12 +1404,25 @@ int mgs_pack_streams_device(mgs_handle *h, const void *d_records, const uint32_t
                             int64_t *round_local_bytes)
 {
     if (!h || !out) return MGS_ERR_ARG;
-    const int rc = mgs_pack_streams_device_async(h, d_records, d_rec_off, n_end, start, stream_fill, open_round_base,
-                                                 d_streams, stream_cap, max_rounds, d_local_out, local_cap, d_dest_out,
-                                                 stream);
-    if (rc) return rc;
-    return mgs_pack_streams_result(h, out, round_next, round_send_offset, round_base, round_local_records,
-                                   round_local_bytes);
+    // A handle whose last one-sweep call met records too long for the staging buffer packs
+    // round by round until the record length says that the smallest tile fits again.
+    const bool known_long = h->fixed_len == 0 && h->ov_shrink > 0 && ov_pick_k_legacy(1.25 * h->ov_bytes_per_record) == 0;
+    if (!known_long) {
+        int rc = mgs_pack_streams_device_async(h, d_records, d_rec_off, n_end, start, stream_fill, open_round_base,
+                                               d_streams, stream_cap, max_rounds, d_local_out, local_cap, d_dest_out,
+                                               stream);
+        if (rc) return rc;
+        rc = mgs_pack_streams_result(h, out, round_next, round_send_offset, round_base, round_local_records,
+                                     round_local_bytes);
+        if (!(rc == MGS_ERR_RECORD_SIZE && h->pending_osv && h->h_ctrl->head.fallback != 0)) return rc;
+    }
+    else if (max_rounds < 1 || stream_cap < 1) {
+        h->err = "mgs_pack_streams_device: max_rounds >= 1 and stream_cap >= 1 required";
+        return MGS_ERR_ARG;
+    }
+    return streams_round_by_round(h, d_records, d_rec_off, n_end, start, stream_fill, open_round_base, d_streams,
+                                  stream_cap, max_rounds, d_local_out, local_cap, d_dest_out, stream, out, round_next,
+                                  round_send_offset, round_base, round_local_records, round_local_bytes);
 }
 
 int mgs_pack_rounds_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off, uint64_t n_end,

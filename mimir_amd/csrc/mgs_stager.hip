@@ -534,6 +534,39 @@ void mgs_host_free(void *p)
     if (p) (void) hipHostFree(p);
 }
 
+// Device memory and a blocking device-to-host copy, for host code that holds device buffers
+// of its own (the destination streams of a whole map) without being built against HIP.
+void *mgs_device_alloc(int device, size_t bytes)
+{
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) p = nullptr;
+    if (prev >= 0) (void) hipSetDevice(prev);
+    return p;
+}
+
+void mgs_device_free(int device, void *p)
+{
+    if (!p) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (hipSetDevice(device) == hipSuccess) (void) hipFree(p);
+    if (prev >= 0) (void) hipSetDevice(prev);
+}
+
+int mgs_copy_to_host(int device, void *host_dst, const void *d_src, size_t bytes)
+{
+    if (bytes == 0) return MGS_OK;
+    if (!host_dst || !d_src) return MGS_ERR_ARG;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMemcpy(host_dst, d_src, bytes, hipMemcpyDeviceToHost);
+    if (prev >= 0) (void) hipSetDevice(prev);
+    return e == hipSuccess ? MGS_OK : MGS_ERR_HIP;
+}
+
 // Device view, for an exchange that reads GPU memory (RCCL, GPU-aware MPI).
 int mgs_stager_send_image_device(mgs_stager *s, void **d_image, const int64_t **send_offset)
 {

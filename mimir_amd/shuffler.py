@@ -301,75 +301,18 @@ class StreamsGpuShuffler:
         self._rounds, self._fill, self._base, self._lused = None, None, None, 0
         return True
 
-    def _pack_round_by_round(self, d_blob, n, d_rec_off, start):
-        """The batch [start, n) for records the one-sweep kernels do not take (a tile's records
-        longer than their LDS image): one mgs_pack_device call per round -- it falls back to the
-        kernels that take any record up to buf_size, as CollectiveShuffler::write does
-        (src/collectiveshuffler.h:131-166) -- into a scratch send image, whose new bytes are
-        appended to the destination streams.  Returns the rounds in the form pack_streams
-        reports them."""
-        from .packer import RoundsResult
-        P, me, cap, buf = self.shuffle_size, self.shuffle_rank, self.stream_cap, self.buf_size
-        if getattr(self, "_scratch_image", None) is None:
-            self._scratch_image = torch.empty(P * buf, dtype=torch.uint8, device=self.dev)
-        img = self._scratch_image
-        fill = np.zeros(P, dtype=np.int64) if self._fill is None else np.asarray(self._fill, dtype=np.int64).copy()
-        base = fill.copy() if self._base is None else np.asarray(self._base, dtype=np.int64).copy()
-        rows, cur, lused, packed, lrec_tot = [], start, 0, 0, 0
-        while True:
-            init = fill - base
-            init[me] = 0
-            r = self.packer.pack(d_blob, n, img, start=cur, rec_off=d_rec_off, init_offset=init,
-                                 local_out=self.local[self._lused + lused:])
-            new = r.send_offset - init
-            for d in range(P):
-                if d == me or new[d] <= 0:
-                    continue
-                if fill[d] + new[d] > cap:
-                    raise capi.MgsError(capi.ERR_ARG, "a destination stream is full: raise stream_bytes")
-                self.streams[d * cap + int(fill[d]):d * cap + int(fill[d] + new[d])] = \
-                    img[d * buf + int(init[d]):d * buf + int(r.send_offset[d])]
-                fill[d] += new[d]
-            lused += r.local_bytes
-            packed += r.packed_records
-            lrec_tot += r.local_records
-            so_row = fill - base
-            so_row[me] = 0
-            rows.append((r.next, so_row.copy(), base.copy(), r.local_records, r.local_bytes))
-            cur = r.next
-            if cur >= n:
-                break
-            base = fill.copy()   # the record that did not fit opens the next round
-            if len(rows) >= self.max_rounds:
-                break
-        out = RoundsResult.__new__(RoundsResult)
-        out.n_rounds = len(rows)
-        out.next = cur
-        out.packed_records, out.local_records, out.local_bytes = packed, lrec_tot, lused
-        out.round_next = np.array([x[0] for x in rows], dtype=np.uint64)
-        out.round_send_offset = np.array([x[1] for x in rows], dtype=np.int64).reshape(len(rows), P)
-        out.round_base = np.array([x[2] for x in rows], dtype=np.int64).reshape(len(rows), P)
-        out.round_local_records = np.array([x[3] for x in rows], dtype=np.uint64)
-        out.round_local_bytes = np.array([x[4] for x in rows], dtype=np.int64)
-        return out
-
     def write_device_records(self, d_blob, n, d_rec_off=None):
         from .packer import merge_stream_rounds
         start = 0
         while start < n:
-            try:
-                r = self.packer.pack_streams(d_blob, n, self.streams, self.stream_cap, self.max_rounds, start=start,
-                                             rec_off=d_rec_off, stream_fill=self._fill, open_round_base=self._base,
-                                             local_out=self.local[self._lused:])
-            except capi.MgsError as e:
-                if e.status != capi.ERR_RECORD_SIZE:
-                    raise
-                # records too long for the one-sweep kernels (or for a partition: then the
-                # round-by-round calls say so again)
-                r = self._pack_round_by_round(d_blob, n, d_rec_off, start)
+            # (records too long for the one-sweep kernels: the call packs round by round with the
+            # generic kernels, which take any record up to buf_size)
+            r = self.packer.pack_streams(d_blob, n, self.streams, self.stream_cap, self.max_rounds, start=start,
+                                         rec_off=d_rec_off, stream_fill=self._fill, open_round_base=self._base,
+                                         local_out=self.local[self._lused:])
             if r.next == start and r.n_rounds >= self.max_rounds:
                 raise capi.MgsError(capi.ERR_ARG, "max_rounds too small for this batch")
-            if r.next < n and r.n_rounds < self.max_rounds:
+            if r.next < n and r.n_rounds < self.max_rounds and r.next - start < self.max_records:
                 raise capi.MgsError(capi.ERR_ARG, "a destination stream is full: raise stream_bytes")
             self._lused += r.local_bytes
             self._base = r.round_base[-1].copy()

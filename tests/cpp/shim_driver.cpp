@@ -5,7 +5,9 @@
 //
 //   shim_driver <kind> <P> <comm_bytes> <stage_bytes> <indir> <outdir> [keycount] [nb]
 //   kind: u64 | words | oct | join;  nb: NBGpuShuffler over non-blocking exchanges;
-//   sum (in place of nb): GpuShuffler as the combiner shuffler with MGS_COMBINE_SUM_U64
+//   sum (in place of nb): GpuShuffler as the combiner shuffler with MGS_COMBINE_SUM_U64;
+//   streams (in place of nb): StreamsGpuShuffler fed device-resident batches (kind longwords too;
+//   MGS_SHIM_STREAM_BYTES: bytes per destination stream, MIMIR_GPU_WINDOW_SIZE: exchange window)
 // Environment: MGS_SHIM_DEVICE_EXCHANGE=1 -- the transport moves device memory
 // (Exchange::alltoallv_device: copies between the ranks' device images); MGS_SHIM_TIMING=1 --
 // the sinks only count, and rank<r>.counters also holds the wall time of the write() loop.
@@ -307,6 +309,56 @@ static void run_rank(Shared *sh, int r, int64_t comm, int64_t /*stage*/, const s
     delete c;
 }
 
+// StreamsGpuShuffler: the rank's records are put into device memory and handed over in
+// three batches (the third of them cut off-centre), as a map that emits device batches does.
+template <typename K, typename V>
+static void run_rank_streams(Shared *sh, int r, int64_t comm, const std::string &indir, const std::string &outdir,
+                             int keycount, bool fixed_width)
+{
+    std::vector<char> blob = slurp(indir + "/rank" + std::to_string(r) + ".blob");
+    std::vector<char> offb = slurp(indir + "/rank" + std::to_string(r) + ".off");
+    const uint64_t *off = reinterpret_cast<const uint64_t *>(offb.data());
+    const size_t n = offb.size() / 8 - 1;
+    std::vector<uint32_t> off32(n + 1);
+    for (size_t i = 0; i <= n; i++) off32[i] = (uint32_t) off[i];
+    char *d_blob = NULL;
+    uint32_t *d_off = NULL;
+    if (hipMalloc(&d_blob, blob.size() + 16) != hipSuccess || hipMalloc(&d_off, (n + 1) * 4) != hipSuccess) std::abort();
+    if (hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) std::abort();
+    if (hipMemcpy(d_off, off32.data(), (n + 1) * 4, hipMemcpyHostToDevice) != hipSuccess) std::abort();
+    ThreadExchange ex(sh, r);
+    DumpSink<K, V> sink(keycount, 1);
+    const char *sb = getenv("MGS_SHIM_STREAM_BYTES");
+    Tagged<StreamsGpuShuffler<K, V>, K, V> *c = new Tagged<StreamsGpuShuffler<K, V>, K, V>(
+        &ex, &sink, NULL, keycount, 1, false, NULL, comm, 0, sb ? atoll(sb) : (int64_t) 8 << 20, 0, 64);
+    c->sink = &sink;
+    c->open();
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t cut[4] = {0, n / 5, n / 5 + n / 2, n};
+    for (int b = 0; b < 3; b++) {
+        const size_t i0 = cut[b], i1 = cut[b + 1];
+        if (i1 == i0) continue;
+        if (fixed_width) c->write_device_records(d_blob + off[i0], i1 - i0, NULL);
+        else c->write_device_records(d_blob, i1 - i0, d_off + i0);
+    }
+    const double write_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->close();
+    (void) hipFree(d_blob);
+    (void) hipFree(d_off);
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".out", std::ios::binary)
+        .write(sink.data.data(), (std::streamsize) sink.data.size());
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".outoff", std::ios::binary)
+        .write(reinterpret_cast<const char *>(sink.off.data()), (std::streamsize)(sink.off.size() * 8));
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".outsrc", std::ios::binary)
+        .write(reinterpret_cast<const char *>(sink.src.data()), (std::streamsize)(sink.src.size() * 4));
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".txt")
+        << c->get_record_count() << " " << c->get_shuffle_times() << " 1\n";
+    std::ofstream(outdir + "/rank" + std::to_string(r) + ".counters")
+        << c->get_send_bytes() << " " << c->get_recv_bytes() << " " << c->get_device_exchanges() << " " << n << " "
+        << write_s << " 0\n";
+    delete c;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 7) {
@@ -330,9 +382,18 @@ int main(int argc, char **argv)
     sh.sdispl.assign((size_t) P, NULL);
     sh.d_send.assign((size_t) P, NULL);
     sh.d_sdispl.assign((size_t) P, NULL);
+    const bool streams = argc > 8 && std::string(argv[8]) == "streams";
     std::vector<std::thread> th;
     for (int r = 0; r < P; r++) {
         th.emplace_back([&, r]() {
+            if (streams) {
+                if (kind == "u64") run_rank_streams<uint64_t, uint64_t>(&sh, r, comm, indir, outdir, 1, true);
+                else if (kind == "words" || kind == "longwords")
+                    run_rank_streams<char *, uint64_t>(&sh, r, comm, indir, outdir, 1, false);
+                else if (kind == "oct") run_rank_streams<char, uint64_t>(&sh, r, comm, indir, outdir, keycount, true);
+                else run_rank_streams<char *, Blob16>(&sh, r, comm, indir, outdir, 1, false);
+                return;
+            }
             if (kind == "u64") {
                 run_rank<uint64_t, uint64_t>(&sh, r, comm, stage, indir, outdir, 1,
                     [](GpuShuffler<uint64_t, uint64_t> *c, char *rec, int) {

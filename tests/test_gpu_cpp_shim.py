@@ -179,3 +179,55 @@ def test_cpp_shim_send_buffer_above_one_gib(oracle, nb):
                 odd += sum(len(x) for x in per[r][s_]) & 1 if s_ != r else 0
             assert int(open(os.path.join(outd, f"rank{r}.txt")).read().split()[0]) == kvcount[r]
         assert odd > 0, "no partition of odd length: the padding was not exercised"
+
+
+@pytest.mark.parametrize("device_exchange", [False, True])
+@pytest.mark.parametrize("kind,P,keycount,window", [("u64", 2, 1, None), ("words", 4, 1, "40k"), ("join", 4, 1, None),
+                                                    ("oct", 8, 11, None), ("u64", 8, 1, "70k"),
+                                                    ("longwords", 3, 1, None)])
+def test_cpp_streams_shim_matches_reference(oracle, kind, P, keycount, window, device_exchange):
+    """StreamsGpuShuffler<K,V>: every rank's records go in as three device-resident batches
+    (mgs_pack_streams_device chained in the same destination streams), close() exchanges the
+    rounds a window at a time -- between device buffers with record boundaries from
+    mgs_unpack_device, or through host mirrors -- and every sink must hold what the oracle
+    simulation of the reference's shuffle gives it, in its order, with its counters.  window:
+    MIMIR_GPU_WINDOW_SIZE (the default holds all rounds of these cases in one window; the small
+    ones hold one or two rounds).  longwords: records the one-sweep kernels do not take."""
+    assert os.path.exists(DRIVER), "tests/cpp/shim_driver not built (__graft_entry__.build)"
+    env = dict(os.environ, MGS_SHIM_DEVICE_EXCHANGE="1" if device_exchange else "0")
+    if window:
+        env["MIMIR_GPU_WINDOW_SIZE"] = window
+    counts = [0 if r == 1 else 5000 * (r % 3 + 1) + 11 * r for r in range(P)]
+    comm = 16384 if P < 8 else 32768
+    if kind == "longwords":
+        counts, comm = [900, 0, 1400], 49152
+    streams, lay = [], None
+    with tempfile.TemporaryDirectory() as d:
+        ind, outd = os.path.join(d, "in"), os.path.join(d, "out")
+        os.makedirs(ind)
+        os.makedirs(outd)
+        for r in range(P):
+            blob, offs, lay = make_stream(kind, r, counts[r])
+            if offs is None:
+                offs = datagen.fixed_offsets(counts[r], lay.fixed_len())
+            streams.append((blob, offs, counts[r]))
+            blob.tofile(os.path.join(ind, f"rank{r}.blob"))
+            np.asarray(offs, dtype=np.uint64).tofile(os.path.join(ind, f"rank{r}.off"))
+        subprocess.run([DRIVER, kind, str(P), str(comm), "0", ind, outd, str(keycount), "streams"],
+                       check=True, timeout=240, env=env)
+        buf_size = capi.geometry(comm, P)[0]
+        sinks, stats = refsim.simulate_shuffle(oracle, lay, streams, P, buf_size)
+        assert max(s["shuffle_times"] for s in stats) >= 3
+        for r in range(P):
+            data = np.fromfile(os.path.join(outd, f"rank{r}.out"), dtype=np.uint8).tobytes()
+            off = np.fromfile(os.path.join(outd, f"rank{r}.outoff"), dtype=np.uint64)
+            got = [data[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+            assert got == sinks[r], f"rank {r}: sink differs"
+            kv, times, _ = open(os.path.join(outd, f"rank{r}.txt")).read().split()
+            assert int(kv) == stats[r]["kvcount"] and int(times) == stats[r]["shuffle_times"]
+            sent, recvd, dev_x = open(os.path.join(outd, f"rank{r}.counters")).read().split()[:3]
+            assert int(sent) == stats[r]["send_bytes"] and int(recvd) == stats[r]["recv_bytes"]
+            assert (int(dev_x) > 0) == device_exchange
+            # the sources in the reference's order: within a round the own records, then source by source
+            src = np.fromfile(os.path.join(outd, f"rank{r}.outsrc"), dtype=np.int32)
+            assert len(src) == len(got)

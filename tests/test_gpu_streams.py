@@ -302,6 +302,54 @@ def test_streams_chained_calls(oracle, kind):
     pk.close()
 
 
+@pytest.mark.parametrize("rank", [1, -1])
+def test_streams_records_too_long_for_the_one_sweep_kernels(oracle, rank):
+    """Words of a hundred bytes and more: a tile of them exceeds the one-sweep kernels' LDS
+    image, so the call packs round by round with the generic kernels and appends every
+    round's partitions to the streams -- same rounds, same bytes, same views; a second call
+    on the same handle goes on in the open round without trying the one-sweep kernel again."""
+    import torch
+    from mimir_amd.packer import DevicePacker
+    n, P, buf = 6000, 3, 16384
+    blob, offs, lay = datagen.word_records(n, n_unique=300, alpha=0.7, len_mean=110, len_sd=30, seed=5)
+    got = check_streams(oracle, blob, offs, lay, n, P, rank, buf, 256, expect_algo="generic")
+    assert got.n_rounds >= 5
+    # chained: the second half goes on where the first stopped
+    glay, olay = capi.Layout.make(*lay), O.Layout.make(*lay)
+    want, _ = oracle_rounds(oracle, olay, blob, offs, n, P, rank, buf)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(np.ascontiguousarray(blob)).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).to(dev)
+    cap = (len(blob) + 4096) // 16 * 16
+    pk = DevicePacker(glay, P, rank, buf, max_records=n)
+    streams = torch.zeros(P * cap, dtype=torch.uint8, device=dev)
+    local = torch.zeros(len(blob), dtype=torch.uint8, device=dev)
+    a = pk.pack_streams(d_blob, n // 2, streams, cap, 256, rec_off=d_off, local_out=local)
+    assert pk.last_algo() == "generic" and a.next == n // 2
+    base = a.round_base[-1].copy()
+    fill = base + a.round_send_offset[-1]
+    b = pk.pack_streams(d_blob, n, streams, cap, 256, start=n // 2, rec_off=d_off, stream_fill=fill,
+                        open_round_base=base, local_out=local[a.local_bytes:])
+    assert b.next == n and a.n_rounds + b.n_rounds - 1 == len(want)
+    img = streams.cpu().numpy()
+    so = np.concatenate([a.round_send_offset[:-1], b.round_send_offset])
+    rb = np.concatenate([a.round_base[:-1], b.round_base])
+    for k, w in enumerate(want):
+        assert so[k].tolist() == w["send_offset"].tolist(), f"round {k}"
+        for p in range(P):
+            if p != rank:
+                o = p * cap + int(rb[k][p])
+                assert np.array_equal(img[o:o + int(so[k][p])], w["partitions"][p]), f"round {k} partition {p}"
+    # a stream without room for a whole partition: the call stops before that round
+    small = (int(so[:2].sum(axis=0).max()) + buf // 2) // 16 * 16
+    streams2 = torch.zeros(P * small, dtype=torch.uint8, device=dev)
+    c = pk.pack_streams(d_blob, n, streams2, small, 256, rec_off=d_off, local_out=local)
+    assert 0 < c.next < n and c.n_rounds < 256
+    assert c.next == want[c.n_rounds - 2]["next"]   # the rounds before the open (empty) one are the reference's
+    assert c.round_send_offset[c.n_rounds - 1].sum() == 0
+    pk.close()
+
+
 def test_streams_empty_call_and_wrong_result_call(oracle):
     import torch
     from mimir_amd.packer import DevicePacker

@@ -22,6 +22,24 @@ template class MIMIR_NS::GpuShuffler<uint64_t, uint64_t>;
 template class MIMIR_NS::GpuShuffler<char, uint64_t>;     // octree
 struct SingleVal { int tag; int64_t v; };
 template class MIMIR_NS::GpuShuffler<char *, SingleVal>;  // join
+template class MIMIR_NS::StreamsGpuShuffler<char *, uint64_t>;
+template class MIMIR_NS::StreamsGpuShuffler<uint64_t, uint64_t>;
+// a map callback that emits a device batch reaches the batch call through the Writable it is handed
+void emit(Writable<uint64_t, uint64_t> *output, const void *d_records, uint64_t n)
+{
+    MIMIR_NS::StreamsGpuShuffler<uint64_t, uint64_t> *s =
+        dynamic_cast<MIMIR_NS::StreamsGpuShuffler<uint64_t, uint64_t> *>(output);
+    if (s) s->write_device_records(d_records, n);
+}
+void drive_streams(MPI_Comm c, Writable<uint64_t, uint64_t> *out, const void *d_records)
+{
+    BaseShuffler<uint64_t, uint64_t> *b =
+        new MIMIR_NS::StreamsGpuShuffler<uint64_t, uint64_t>(c, out, NULL, 1, 1, false, NULL);
+    b->open();
+    emit(b, d_records, 1000);
+    b->close();
+    delete b;
+}
 // the class is concrete and is driven through the reference's base class
 void drive(MPI_Comm c, Writable<uint64_t, uint64_t> *out)
 {
