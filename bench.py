@@ -67,6 +67,51 @@ def cpu_baseline(records_dev, n_total, target_seconds=12.0):
                       f"CollectiveShuffler::write) on one host core, {dt:.1f} s"}
 
 
+def cpu_baseline_ref_pieces(records_dev, n_total, target_seconds=6.0):
+    """The same loop with the reference's own compiled pieces -- Serializer::get_hash_code ->
+    hashlittle, modulo, Serializer::kv_to_bytes (oracle/_ref/libmimir_ref_ser.so, built in the
+    build container from the sources under /root/reference) -- on one host core, on a prefix
+    of the records the GPU packed, checked against the port's partitions.  None where the
+    library is absent or does not load."""
+    import numpy as np
+    from oracle import oracle as O
+    try:
+        ref = O.ReferenceSerializer()
+    except (OSError, FileNotFoundError) as e:
+        print(f"# reference pieces not timed: {e}", file=sys.stderr)
+        return None
+    P = 8
+
+    def run(n, check=False):
+        blob = records_dev[:16 * n].cpu().numpy()
+        buf = 16 * (n // P + n // 64 + 4096)
+        img = np.zeros(P * buf, dtype=np.uint8)
+        so = np.zeros(P, dtype=np.int64)
+        t0 = time.perf_counter()
+        done = ref.write_loop_u64_u64(blob, n, P, img, buf, so)
+        dt = time.perf_counter() - t0
+        assert done == n
+        if check:  # the port gives the same partitions
+            orc = O.Oracle()
+            lay = O.Layout.make(O.KEY_FIXED, 8, O.VAL_FIXED, 8)
+            want = orc.pack_round(lay, blob, None, n, 0, P, -1, buf)
+            assert want["send_offset"].tolist() == so.tolist()
+            for d in range(P):
+                assert np.array_equal(img[d * buf:d * buf + int(so[d])], want["partitions"][d])
+        return dt
+
+    n0 = min(1 << 21, n_total)
+    dt0 = run(n0, check=True)
+    n = int(min(max(n0, n0 * target_seconds / max(dt0, 1e-6)), n_total))
+    dt = run(n)
+    return {"value": n / dt, "unit": "records/s", "cores": 1, "kind": "ref-pieces",
+            "GBps": n * ALGO_BYTES_PER_RECORD / dt / 1e9,
+            "sample": f"first {n} of the benchmark's own <u64,u64> records, P=8, one round: the reference's "
+                      f"compiled Serializer::get_hash_code (hashlittle) % P and Serializer::kv_to_bytes per "
+                      f"record (oracle/ref_probe_ser.cpp ser_write_loop_u64_u64) on one host core, {dt:.1f} s; "
+                      f"partitions equal the port's on the first {n0}"}
+
+
 def cpu_baseline_multicore(n_total):
     """The same loop on every physical core this job may use (one process per
     core, each a rank with its own slice and its own send image), run as a child
@@ -554,6 +599,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": committed_traffic(kernel, n, stats["rounds"]) if not distributed else None,
+                     "traffic_source": ("profiles/pmc_traffic.json (committed rocprofv3 PMC passes of this "
+                                        "command; not collected by this run)"
+                                        if not distributed and committed_traffic(kernel, n, stats["rounds"]) else None),
                      "kernel": kernel, "kernel_ms": k_ms,
                      "algorithmic_bytes_per_launch": algo_bytes},
     }
@@ -587,6 +635,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline_multicore(n) or single
         out["cpu_baseline"]["single_core"] = {k: single[k] for k in ("value", "unit", "GBps", "sample")}
         out["cpu_baseline"].setdefault("host_cpus", host_cpus())
+        out["cpu_baseline"]["reference_pieces"] = cpu_baseline_ref_pieces(records, n)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -363,7 +363,16 @@ class ReferenceSerializer:
         L.ser_hash_chars.argtypes = [C.c_char_p, C.c_int]
         L.ser_kv_cstr_blob16.restype = C.c_int
         L.ser_kv_cstr_blob16.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.ser_write_loop_u64_u64.restype = C.c_long
+        L.ser_write_loop_u64_u64.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_void_p]
         self.L = L
+
+    def write_loop_u64_u64(self, pairs, n, nranks, send_buffer, buf_size, send_offset):
+        """CollectiveShuffler::write's per-record work (src/collectiveshuffler.h:131-166) over
+        n <u64,u64> pairs with the reference's compiled get_hash_code / hashlittle /
+        kv_to_bytes: numpy arrays in, pairs packed out (stops at the first that does not fit)."""
+        return self.L.ser_write_loop_u64_u64(pairs.ctypes.data, n, nranks, send_buffer.ctypes.data, buf_size,
+                                             send_offset.ctypes.data)
 
     @staticmethod
     def _run(fn, args, bufsize, room=4096):

@@ -116,4 +116,28 @@ int ser_kv_cstr_blob16(const char *key, const void *val16, char *buf, int bufsiz
     return raw.get(1, 1)->kv_to_bytes(&k, &v, buf, bufsize);
 }
 
+// The per-record work of CollectiveShuffler::write (src/collectiveshuffler.h:131-166) for
+// <uint64_t, uint64_t> pairs with the reference's own compiled pieces in the reference's
+// order: get_hash_code (-> hashlittle, src/hash.cpp) modulo the rank count
+// (src/baseshuffler.h:268-309), then kv_to_bytes into the target's partition at its
+// send_offset.  The loop around them is this file's; it stops at the first pair that does
+// not fit (where the reference starts an exchange) and returns how many pairs it packed.
+// For timing the reference's code on the host beside the C restatement.
+long ser_write_loop_u64_u64(const uint64_t *pairs, long n, int nranks, char *send_buffer, long buf_size,
+                            int64_t *send_offset)
+{
+    RawSerializer<uint64_t, uint64_t> raw;
+    Serializer<uint64_t, uint64_t> *ser = raw.get(1, 1);
+    long i = 0;
+    for (; i < n; i++) {
+        uint64_t key = pairs[2 * i], val = pairs[2 * i + 1];
+        const int target = (int) (ser->get_hash_code(&key) % (uint32_t) nranks);
+        char *buffer = send_buffer + (int64_t) target * buf_size + send_offset[target];
+        const int kvsize = ser->kv_to_bytes(&key, &val, buffer, (int) (buf_size - send_offset[target]));
+        if (kvsize == -1) break;
+        send_offset[target] += kvsize;
+    }
+    return i;
+}
+
 } // extern "C"
