@@ -90,7 +90,7 @@ def cpu_baseline_ref_pieces(records_dev, n_total, target_seconds=6.0):
         t0 = time.perf_counter()
         done = ref.write_loop_u64_u64(blob, n, P, img, buf, so)
         dt = time.perf_counter() - t0
-        assert done == n
+        assert done == n, (done, n, so.tolist(), buf)
         if check:  # the port gives the same partitions
             orc = O.Oracle()
             lay = O.Layout.make(O.KEY_FIXED, 8, O.VAL_FIXED, 8)
@@ -102,7 +102,8 @@ def cpu_baseline_ref_pieces(records_dev, n_total, target_seconds=6.0):
 
     n0 = min(1 << 21, n_total)
     dt0 = run(n0, check=True)
-    n = int(min(max(n0, n0 * target_seconds / max(dt0, 1e-6)), n_total))
+    # (kv_to_bytes takes the room left in a partition as an int: partitions stay below 2 GiB)
+    n = int(min(max(n0, n0 * target_seconds / max(dt0, 1e-6)), n_total, 400_000_000))
     dt = run(n)
     return {"value": n / dt, "unit": "records/s", "cores": 1, "kind": "ref-pieces",
             "GBps": n * ALGO_BYTES_PER_RECORD / dt / 1e9,
