@@ -500,9 +500,12 @@ def main():
         dt = float(t.item())
 
     # ---- N > 1, after the timed region: the two exchange protocols side by side, what the
-    # overlap hid, and the end-to-end check of what arrived
+    # overlap hid, and the end-to-end check of what arrived (run below, once the line that holds
+    # the measurement is complete, under a watchdog: a hang or an error in here must not
+    # lose the measurement)
     extra = {}
-    if distributed and streams_layout and "last" in stats:
+
+    def post_timing_extras():
         r_last = stats["last"][0]
         so_l, base_l = r_last.round_send_offset, r_last.round_base
         src_img = images.cpu() if backend == "gloo" else images
@@ -555,6 +558,7 @@ def main():
                         raise RuntimeError(f"rank {rank}: the windowed exchange delivered other bytes from source {s_}")
                 extra["windows_equal_batch"] = True
                 del keep
+
 
     ms_per_step = dt / args.steps * 1e3
     value = n * chunks * world * args.steps / dt
@@ -624,6 +628,31 @@ def main():
                            "exchange_ms": xfer_s * 1e3,
                            "xgmi_floor_ms": hot / (XGMI_LINK_GBS * 1e9) * 1e3,
                            "frac_of_xgmi_pair_roofline": (hot / (XGMI_LINK_GBS * 1e9)) / max(xfer_s, 1e-9)}
+        if streams_layout and "last" in stats:
+            import threading
+            limit = float(os.environ.get("MGS_BENCH_EXTRAS_TIMEOUT", "300"))
+
+            def bail():
+                # the measurement stands; say what is missing and leave (peers do the same)
+                if rank == 0:
+                    out["exchange"].update(extra)
+                    out["exchange"]["post_timing"] = (f"the comparison of the exchange protocols / the verification "
+                                                      f"did not finish within {limit:.0f} s and was abandoned")
+                    out["cpu_baseline"] = None
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+            dog = threading.Timer(limit, bail)
+            dog.daemon = True
+            dog.start()
+            try:
+                post_timing_extras()
+            except Exception as e:  # a rank that fails leaves its peers in a collective: the watchdog ends them
+                extra["post_timing_error"] = repr(e)[:400]
+                print(f"# rank {rank}: {e!r}", file=sys.stderr, flush=True)
+                if world > 1:
+                    dog.join()      # leave through the watchdog together with the peers
+            dog.cancel()
         out["exchange"].update(extra)
         if "batch_ms" in extra:
             # pack alone + the whole batch as one exchange, against the step as it ran

@@ -469,7 +469,8 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes,
  * reference sizes the slices with a stale length, :84-94, so there is no
  * defined result to match).  MGS_ERR_ARG when there are more groups than
  * group_capacity or more cuts than max_cuts.  Blocking.  The stable sort of
- * (group, record) pairs inside is rocPRIM's radix sort. */
+ * the records by group inside is a radix sort whose passes are launches of the
+ * library's own 16-byte partition kernel (no external sort library). */
 int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec_off,
                      uint64_t n_records, uint32_t *d_group_first, uint32_t *d_group_start,
                      uint64_t group_capacity, void *d_values, int64_t page_bytes,

@@ -1798,21 +1798,19 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
     p.max_cuts = kUnpMaxCuts;
     p.ctrl = h->d_ctrl;
 
-    size_t sort_bytes = 0;
-    {
-        const hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr,
-                                                       rocprim::counting_iterator<uint32_t>(0), (uint32_t *) nullptr,
-                                                       (size_t) n_records, 0u, 32u, stream);
-        if (e != hipSuccess) {
-            h->err = fmt("rocprim::radix_sort_pairs (size query) failed: %s", hipGetErrorString(e));
-            return MGS_ERR_HIP;
-        }
-    }
+    // the sort: passes of the 16-byte one-sweep kernel over {rank, record, value} records
+    const OsVariant &SV = *os16_digit_variant();
+    const uint32_t sort_tiles = (uint32_t) ((n_records + (uint64_t) SV.tile - 1) / (uint64_t) SV.tile);
+    const size_t sort_status = (size_t) sort_tiles * GRP_SORT_BINS * sizeof(unsigned long long);
+    const size_t sort_agg = (size_t) sort_tiles * (GRP_SORT_BINS / 4) * sizeof(unsigned long long);
+    const size_t sort_rt = 2 * ((size_t) GRP_SORT_BINS + 1) * sizeof(unsigned long long);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t need = up((2 + kUnpMaxCuts) * sizeof(uint64_t)) + 3 * up(slots * sizeof(uint32_t))
-                        + 3 * up((size_t) n_records * sizeof(uint32_t)) + up(((size_t) p.ntiles + 1) * sizeof(uint32_t))
+    const size_t need = up((2 + kUnpMaxCuts) * sizeof(uint64_t)) + 5 * up(slots * sizeof(uint32_t))
+                        + up((size_t) n_records * sizeof(uint32_t)) + 2 * up((size_t) n_records * sizeof(uint4))
+                        + up(((size_t) p.ntiles + 1) * sizeof(uint32_t))
                         + up((size_t) p.ntiles * (GRP_TILE / 64) * sizeof(uint64_t))
-                        + up(sort_bytes);
+                        + up(GRP_SORT_MAX_PASSES * GRP_SORT_BINS * sizeof(uint32_t)) + up(GRP_SORT_MAX_PASSES * sizeof(Ctrl))
+                        + up(sort_status) + up(sort_agg) + up(sort_rt);
     if (h->pending) { // the control block and the scratch are shared with the pack call in flight
         h->err = "mgs_group_device: a pack call is in flight on this handle (call mgs_pack_result first)";
         return MGS_ERR_STATE;
@@ -1830,25 +1828,36 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
     uint8_t *q = h->d_grp;
     p.result = reinterpret_cast<uint64_t *>(q);
     p.cuts = p.result + 2;                               q += up((2 + kUnpMaxCuts) * sizeof(uint64_t));
-    p.table = reinterpret_cast<unsigned long long *>(q); q += up(slots * sizeof(unsigned long long));
+    p.table = reinterpret_cast<unsigned long long *>(q); q += 2 * up(slots * sizeof(unsigned long long));
+    // string keys (wordcount, join: many records per key) keep the key's first bytes in the slot;
+    // for fixed-width keys the larger table costs more than the saved look-ups into the stream
+    p.table_stride = L.key_kind == MGS_KEY_CSTR ? 2 : 1;
+    p.cand_bit = 0x80000000u;
     p.rank_table = reinterpret_cast<uint32_t *>(q);      q += up(slots * sizeof(uint32_t));
     p.slot_or_rank = reinterpret_cast<uint32_t *>(q);    q += up((size_t) n_records * sizeof(uint32_t));
-    p.sorted_rank = reinterpret_cast<uint32_t *>(q);     q += up((size_t) n_records * sizeof(uint32_t));
-    p.sorted_rec = reinterpret_cast<uint32_t *>(q);      q += up((size_t) n_records * sizeof(uint32_t));
+    p.rec_a = reinterpret_cast<uint4 *>(q);              q += up((size_t) n_records * sizeof(uint4));
+    p.rec_b = reinterpret_cast<uint4 *>(q);              q += up((size_t) n_records * sizeof(uint4));
     p.tile_count = reinterpret_cast<uint32_t *>(q);      q += up(((size_t) p.ntiles + 1) * sizeof(uint32_t));
     p.first_bits = reinterpret_cast<uint64_t *>(q);      q += up((size_t) p.ntiles * (GRP_TILE / 64) * sizeof(uint64_t));
-    void *sort_tmp = q;
+    p.hist = reinterpret_cast<uint32_t *>(q);            q += up(GRP_SORT_MAX_PASSES * GRP_SORT_BINS * sizeof(uint32_t));
+    p.sort_ctrl = reinterpret_cast<Ctrl *>(q);           q += up(GRP_SORT_MAX_PASSES * sizeof(Ctrl));
+    unsigned long long *d_sort_status = reinterpret_cast<unsigned long long *>(q); q += up(sort_status);
+    unsigned long long *d_sort_agg = reinterpret_cast<unsigned long long *>(q);    q += up(sort_agg);
+    unsigned long long *d_sort_rt = reinterpret_cast<unsigned long long *>(q);     q += up(sort_rt);
 
     const unsigned wide = (unsigned) std::min<uint64_t>((n_records + GRP_THREADS - 1) / GRP_THREADS,
                                                         (uint64_t) std::max(h->num_cus, 1) * 32);
     MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
     MGS_HIP(h, hipMemsetAsync(p.result, 0, 2 * sizeof(uint64_t), stream));
-    MGS_HIP(h, hipMemsetAsync(p.table, 0xFF, slots * sizeof(unsigned long long), stream));
+    MGS_HIP(h, hipMemsetAsync(p.table, 0xFF, (size_t) p.table_stride * slots * sizeof(unsigned long long), stream));
+    MGS_HIP(h, hipMemsetAsync(p.hist, 0, GRP_SORT_MAX_PASSES * GRP_SORT_BINS * sizeof(uint32_t), stream));
+    MGS_HIP(h, hipMemsetAsync(p.sort_ctrl, 0, GRP_SORT_MAX_PASSES * sizeof(Ctrl), stream));
     hipLaunchKernelGGL(k_grp_insert, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
     hipLaunchKernelGGL(k_grp_count, dim3(p.ntiles), dim3(GRP_THREADS), 0, stream, p);
     hipLaunchKernelGGL(k_grp_scan, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(k_grp_rank, dim3(p.ntiles), dim3(GRP_THREADS), 0, stream, p);
     hipLaunchKernelGGL(k_grp_keys, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(k_grp_sort_setup, dim3(1), dim3(64), 0, stream, p);
     MGS_HIP(h, hipGetLastError());
     // the sort needs only the bits the ranks use: fetch the number of groups
     MGS_HIP(h, hipMemcpyAsync(h->h_unp, p.result, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
@@ -1858,15 +1867,38 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
     const uint64_t G = h->h_unp[0];
     int derr = h->h_ctrl->head.error;
     if (derr == 0) {
-        unsigned bits = 1;
-        while (bits < 32 && (1ull << bits) < G) bits++;
-        const hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, (const uint32_t *) p.slot_or_rank, p.sorted_rank,
-                                                       rocprim::counting_iterator<uint32_t>(0), p.sorted_rec,
-                                                       (size_t) n_records, 0u, bits, stream);
-        if (e != hipSuccess) {
-            h->err = fmt("rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
-            return MGS_ERR_HIP;
+        // stable radix sort of the sort records on the ranks' bits, least significant digit first
+        const GrpSortPlan plan = grp_sort_plan(G);
+        for (int s = 0; s < plan.npass; s++) {
+            OsParams sp;
+            memset(&sp, 0, sizeof(sp));
+            sp.rec = (s & 1) ? p.rec_b : p.rec_a;
+            sp.n = n_records;
+            sp.first = 0;
+            sp.P = 1u << plan.width[s];
+            sp.self = -1;
+            sp.klen = plan.shift[s];      // OSV_DIGIT: the digit's shift ...
+            sp.kmask[0] = sp.P - 1u;      // ... and mask
+            sp.nbits = plan.width[s];
+            sp.nbits_pad = sp.nbits;
+            sp.fm = make_fastmod(sp.P);
+            sp.tile_records = (uint32_t) SV.tile;
+            sp.ntiles = sort_tiles;
+            sp.status = d_sort_status;
+            sp.agg16 = d_sort_agg;
+            sp.lpt_log = sp.nbits_pad > 2 ? sp.nbits_pad - 2 : 0;
+            sp.unit_shift = 4;
+            sp.ctrl = p.sort_ctrl + s;
+            sp.rt = d_sort_rt;
+            sp.rt_start = sp.rt + 2 * (size_t) sp.P;
+            sp.max_rounds = 1;
+            MGS_HIP(h, hipMemsetAsync(d_sort_status, 0, (size_t) sort_tiles * sp.P * sizeof(unsigned long long), stream));
+            MGS_HIP(h, hipMemsetAsync(d_sort_agg, 0, ((size_t) sort_tiles << sp.lpt_log) * sizeof(unsigned long long), stream));
+            MGS_HIP(h, hipMemsetAsync(d_sort_rt, 0, 2 * ((size_t) sp.P + 1) * sizeof(unsigned long long), stream));
+            const uint32_t grid = std::min<uint32_t>(sort_tiles, (uint32_t) (h->num_cus * SV.blocks_per_cu));
+            hipLaunchKernelGGL(SV.kernel[sp.nbits], dim3(grid), dim3(SV.threads), 0, stream, sp);
         }
+        p.sorted = (plan.npass & 1) ? p.rec_b : p.rec_a;
         hipLaunchKernelGGL(k_grp_emit, dim3(wide), dim3(GRP_THREADS), 0, stream, p);
         hipLaunchKernelGGL(k_grp_pages, dim3(1), dim3(64), 0, stream, p);
         MGS_HIP(h, hipGetLastError());
@@ -1983,6 +2015,7 @@ int mgs_combine_device(mgs_handle *h, const void *d_records, const uint32_t *d_r
     uint8_t *w = h->d_grp;
     p.end = reinterpret_cast<unsigned long long *>(w);         w += up(sizeof(unsigned long long));
     q.table = reinterpret_cast<unsigned long long *>(w);       w += up(slots * sizeof(unsigned long long));
+    q.table_stride = 1;
     q.rank_table = reinterpret_cast<uint32_t *>(w);            w += up(slots * sizeof(uint32_t));
     q.slot_or_rank = reinterpret_cast<uint32_t *>(w);          w += up(n * sizeof(uint32_t));
     p.pos = reinterpret_cast<uint32_t *>(w);                   w += up(n * sizeof(uint32_t));

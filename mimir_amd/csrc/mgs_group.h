@@ -27,15 +27,19 @@
 //                 a record is a first occurrence iff its slot holds its own
 //                 place; prefix sum over those flags = the group's rank, left in
 //                 a second table by the first record
-//   k_grp_keys    rank of every record's group (the sort key)
-//   (library)     stable radix sort of (rank, record index) pairs on the bits
-//                 the ranks need (rocPRIM; the one library primitive here)
-//   k_grp_emit    values in sorted order; group boundaries
+//   k_grp_keys    rank of every record's group (the sort key), left with the record's
+//                 index and the first 8 bytes of its value as a 16-byte sort record;
+//                 histograms of the ranks' digits
+//   (sort)        stable least-significant-digit radix sort of those records on the
+//                 bits the ranks need: passes of at most 6 bits, each pass one launch
+//                 of the 16-byte one-sweep partition kernel with the digit as the
+//                 destination (mgs_onesweep16w.h, OSV_DIGIT) and the partitions laid
+//                 end to end by k_grp_sort_setup
+//   k_grp_emit    values in sorted order (out of the sort records when a value is at
+//                 most 8 bytes long: no gather); group boundaries
 //   k_grp_pages   value-buffer cuts, 64 probes per search step
 #ifndef MGS_GROUP_H
 #define MGS_GROUP_H
-
-#include <rocprim/rocprim.hpp>
 
 #include "mgs_generic.h"
 
@@ -44,6 +48,30 @@ namespace mgs {
 constexpr uint32_t GRP_EMPTY = 0xFFFFFFFFu;
 constexpr unsigned long long GRP_EMPTY64 = ~0ull;
 constexpr int GRP_THREADS = 256, GRP_ITEMS = 8, GRP_TILE = GRP_THREADS * GRP_ITEMS;
+constexpr int GRP_SORT_MAX_PASSES = 6, GRP_SORT_BINS = 64;
+
+// How ranks in [0, groups) are sorted: npass passes from the least significant bits up,
+// pass i on width[i] <= 6 bits at shift[i] (the widths differ by at most one).
+struct GrpSortPlan {
+    int npass;
+    uint32_t shift[GRP_SORT_MAX_PASSES], width[GRP_SORT_MAX_PASSES];
+};
+
+__host__ __device__ inline GrpSortPlan grp_sort_plan(uint64_t groups)
+{
+    GrpSortPlan s;
+    uint32_t bits = 1;
+    while (bits < 32 && (1ull << bits) < groups) bits++;
+    s.npass = (int) ((bits + 5) / 6);
+    const uint32_t base = bits / (uint32_t) s.npass, extra = bits % (uint32_t) s.npass;
+    uint32_t sh = 0;
+    for (int i = 0; i < GRP_SORT_MAX_PASSES; i++) {
+        s.width[i] = i < s.npass ? base + ((uint32_t) i < extra ? 1u : 0u) : 0u;
+        s.shift[i] = sh;
+        sh += s.width[i];
+    }
+    return s;
+}
 
 struct GrpParams {
     const uint8_t *blob;
@@ -52,12 +80,24 @@ struct GrpParams {
     uint32_t n;              // records
     mgs_layout lay;
     uint32_t vbytes;         // value bytes per record (0 = no value)
-    unsigned long long *table; // [slots] hash << 32 | place of the first record with a key (grp_place), or GRP_EMPTY64
+    // [slots * table_stride] per slot: hash << 32 | place of the first record with a key (grp_place), or
+    // GRP_EMPTY64; with table_stride == 2 followed by the key's first 8 bytes (zero-padded; GRP_EMPTY64 =
+    // not written yet), so that most keys are compared without a second, dependent read into the stream
+    unsigned long long *table;
+    uint32_t table_stride;   // 1 or 2
     uint32_t *rank_table;    // [slots] rank of the key's group
     uint32_t slot_mask, slot_shift;
-    uint32_t *slot_or_rank;  // [n] slot of record i, later the rank of its group
-    uint32_t *sorted_rank;   // [n]
-    uint32_t *sorted_rec;    // [n]
+    uint32_t *slot_or_rank;  // [n] slot of record i (| cand_bit, see there)
+    // 0x80000000 or 0: with the bit, k_grp_insert marks in slot_or_rank the records that may be the
+    // first with their key (they opened their slot or lowered its place); a record that met an
+    // earlier one is never the first, so k_grp_count looks only the marked ones up again
+    uint32_t cand_bit;
+    // sort records {rank of the group, record index, first 8 value bytes}: pass 0 reads rec_a and
+    // writes rec_b, pass 1 the other way round, ...; `sorted` is where the last pass left them
+    uint4 *rec_a, *rec_b;
+    const uint4 *sorted;
+    uint32_t *hist;          // [GRP_SORT_MAX_PASSES][GRP_SORT_BINS] records per digit value and pass
+    Ctrl *sort_ctrl;         // [GRP_SORT_MAX_PASSES] control blocks of the passes
     uint32_t *tile_count;    // [ntiles + 1] first occurrences per tile, then exclusive sums (+ total)
     uint64_t *first_bits;    // [ntiles * GRP_TILE / 64] bit i: record i is the first with its key
     uint32_t ntiles;
@@ -139,22 +179,49 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_insert(GrpParams p)
         uint32_t s = (h * 0x9E3779B1u) >> p.slot_shift;
         const uint32_t place = grp_place(p, i);
         const unsigned long long mine = ((unsigned long long) h << 32) | place;
-        for (uint32_t probes = 0; probes <= p.slot_mask; probes++) { // the table is at most half full
-            unsigned long long cur = __hip_atomic_load(p.table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == GRP_EMPTY64) {
-                cur = atomicCAS(p.table + s, GRP_EMPTY64, mine);
-                if (cur == GRP_EMPTY64) break; // this record opened the slot
+        const uint32_t ts = p.table_stride;
+        unsigned long long k8 = 0; // the key's first 8 bytes, zero-padded
+        if (ts == 2) {
+            if ((uint64_t) (key - p.blob) + 8 <= blob_bytes) {
+                k8 = reinterpret_cast<const GrpU64 *>(key)->v;
+                if (klen < 8) k8 &= (1ull << (8 * klen)) - 1ull;
             }
-            if ((uint32_t) (cur >> 32) == h) { // same hash: compare the keys in the stream
-                const uint8_t *okey = grp_key_at(p, (uint32_t) cur);
-                if (cur == mine || grp_same_key(key, klen, okey, blob_bytes - (uint64_t) (okey - p.blob))) {
-                    if (mine < cur) atomicMin(p.table + s, mine); // the slot keeps the first occurrence
+            else {
+                for (uint32_t b = 0; b < klen && b < 8; b++) k8 |= (unsigned long long) key[b] << (8 * b);
+            }
+        }
+        bool cand = false;
+        for (uint32_t probes = 0; probes <= p.slot_mask; probes++) { // the table is at most half full
+            unsigned long long *e = p.table + (size_t) s * ts;
+            unsigned long long cur = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long cur8 = ts == 2 ? __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : GRP_EMPTY64;
+            if (cur == GRP_EMPTY64) {
+                cur = atomicCAS(e, GRP_EMPTY64, mine);
+                if (cur == GRP_EMPTY64) { // this record opened the slot
+                    if (ts == 2) __hip_atomic_store(e + 1, k8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cand = true;
+                    break;
+                }
+                cur8 = GRP_EMPTY64; // opened by another record just now: its key bytes may not be there yet
+            }
+            if ((uint32_t) (cur >> 32) == h) { // same hash: compare the keys
+                bool same;
+                if (cur == mine) same = true;
+                else if (cur8 != GRP_EMPTY64 && cur8 != k8) same = false;
+                else if (cur8 != GRP_EMPTY64 && klen <= 8) same = true; // all of the key is in the slot
+                else { // in the stream itself
+                    const uint8_t *okey = grp_key_at(p, (uint32_t) cur);
+                    same = grp_same_key(key, klen, okey, blob_bytes - (uint64_t) (okey - p.blob));
+                }
+                if (same) {
+                    if (mine < cur) atomicMin(e, mine); // the slot keeps the first occurrence
+                    cand = mine <= cur;
                     break;
                 }
             }
             s = (s + 1) & p.slot_mask;
         }
-        p.slot_or_rank[i] = s;
+        p.slot_or_rank[i] = s | (cand ? p.cand_bit : 0u);
     }
 }
 
@@ -169,7 +236,12 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_count(GrpParams p)
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; k++) {
         const uint64_t i = t0 + (uint64_t) k * GRP_THREADS + threadIdx.x;
-        const bool first = i < p.n && (uint32_t) p.table[p.slot_or_rank[i]] == grp_place(p, i);
+        bool first = false;
+        if (i < p.n) {
+            const uint32_t sl = p.slot_or_rank[i];
+            if (p.cand_bit == 0 || (sl & p.cand_bit) != 0)
+                first = (uint32_t) p.table[(size_t) (sl & ~p.cand_bit) * p.table_stride] == grp_place(p, i);
+        }
         const uint64_t bits = __ballot(first);
         if (lane == 0) p.first_bits[(t0 + (uint64_t) k * GRP_THREADS) / 64 + w] = bits;
         c += (uint32_t) __popcll(bits);
@@ -238,16 +310,67 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_rank(GrpParams p)
         const uint64_t bits = word[wi];
         if ((bits >> lane) & 1ull) {
             const uint64_t i = t0 + (uint64_t) wi * 64 + lane;
-            p.rank_table[p.slot_or_rank[i]] = base + before[wi] + (uint32_t) __popcll(bits & ((1ull << lane) - 1ull));
+            p.rank_table[p.slot_or_rank[i] & ~p.cand_bit] = base + before[wi] + (uint32_t) __popcll(bits & ((1ull << lane) - 1ull));
         }
     }
 }
 
+// Every record's sort record and the digit histograms of all passes (the number of groups
+// is known on the device by now: k_grp_scan).
 __global__ __launch_bounds__(GRP_THREADS) void k_grp_keys(GrpParams p)
 {
+    __shared__ uint32_t hist[GRP_SORT_MAX_PASSES * GRP_SORT_BINS];
+    if (p.ctrl->head.error != 0) return; // a malformed record: its value must not be looked for
+    for (int j = threadIdx.x; j < GRP_SORT_MAX_PASSES * GRP_SORT_BINS; j += GRP_THREADS) hist[j] = 0;
+    __syncthreads();
+    const GrpSortPlan plan = grp_sort_plan(p.result[0]);
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride)
-        p.slot_or_rank[i] = p.rank_table[p.slot_or_rank[i]];
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+        const uint32_t rank = p.rank_table[p.slot_or_rank[i] & ~p.cand_bit];
+        unsigned long long v = 0;
+        if (p.vbytes) {
+            const uint8_t *src = p.blob + grp_offset(p, i + 1) - p.vbytes; // the value ends the record
+            if (p.vbytes >= 8) v = reinterpret_cast<const GrpU64 *>(src)->v;
+            else
+                for (uint32_t b = 0; b < p.vbytes; b++) v |= (unsigned long long) src[b] << (8 * b);
+        }
+        p.rec_a[i] = make_uint4(rank, (uint32_t) i, (uint32_t) v, (uint32_t) (v >> 32));
+        // one LDS add per distinct digit value of the wave (skewed ranks put most lanes on one value)
+        const uint64_t active = __ballot(true);
+        for (int s = 0; s < plan.npass; s++) {
+            const uint32_t d = (rank >> plan.shift[s]) & ((1u << plan.width[s]) - 1u);
+            uint64_t m = active;
+#pragma unroll
+            for (uint32_t bit = 0; bit < 6; bit++) {
+                const bool one = (d >> bit) & 1u;
+                const uint64_t bk = __ballot(one);
+                m &= one ? bk : ~bk;
+            }
+            if (lanes_below(m) == 0) atomicAdd(&hist[s * GRP_SORT_BINS + d], (uint32_t) __popcll(m));
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < GRP_SORT_MAX_PASSES * GRP_SORT_BINS; j += GRP_THREADS)
+        if (hist[j]) atomicAdd(&p.hist[j], hist[j]);
+}
+
+// One wave: the partitions of every pass, end to end in the order of the digit's values.
+__global__ __launch_bounds__(64) void k_grp_sort_setup(GrpParams p)
+{
+    const GrpSortPlan plan = grp_sort_plan(p.result[0]);
+    const int lane = threadIdx.x;
+    for (int s = 0; s < plan.npass; s++) {
+        const uint32_t bins = 1u << plan.width[s];
+        const uint32_t c = (uint32_t) lane < bins ? p.hist[s * GRP_SORT_BINS + lane] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(c, lane);
+        uint4 *out = (s & 1) ? p.rec_a : p.rec_b;
+        CtrlHead &H = p.sort_ctrl[s].head;
+        if ((uint32_t) lane < bins) {
+            H.part_base[lane] = (uint64_t) (uintptr_t) (out + (incl - c));
+            H.part_cap[lane] = (int64_t) c * 16;
+            H.part_init[lane] = 0;
+        }
+    }
 }
 
 // One thread per sorted position: the record's value, and the group's entry
@@ -255,20 +378,38 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_keys(GrpParams p)
 __global__ __launch_bounds__(GRP_THREADS) void k_grp_emit(GrpParams p)
 {
     if (p.ctrl->head.error != 0) return;
+    for (int s = 0; s < GRP_SORT_MAX_PASSES; s++) { // a sort pass that gave up: nothing is sorted
+        const int e = p.sort_ctrl[s].head.error;
+        if (e != 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) raise_error(p.ctrl, e);
+            return;
+        }
+    }
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
     for (uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += stride) {
-        const uint32_t g = p.sorted_rank[j], i = p.sorted_rec[j];
-        if (j == 0 || p.sorted_rank[j - 1] != g) {
+        const uint4 r = p.sorted[j];
+        const uint32_t g = r.x, i = r.y;
+        if (j == 0 || p.sorted[j - 1].x != g) {
             p.group_first[g] = i;
             p.group_start[g] = (uint32_t) j;
         }
         if (p.vbytes) {
-            const uint8_t *src = p.blob + grp_offset(p, (uint64_t) i + 1) - p.vbytes; // the value ends the record
             uint8_t *dst = p.values + j * p.vbytes;
-            uint32_t b = 0;
-            for (; b + 8 <= p.vbytes; b += 8)
-                reinterpret_cast<GrpU64 *>(dst + b)->v = reinterpret_cast<const GrpU64 *>(src + b)->v;
-            for (; b < p.vbytes; b++) dst[b] = src[b];
+            const unsigned long long v = ((unsigned long long) r.w << 32) | r.z;
+            if (p.vbytes == 8) {
+                reinterpret_cast<GrpU64 *>(dst)->v = v;
+            }
+            else if (p.vbytes < 8) {
+                for (uint32_t b = 0; b < p.vbytes; b++) dst[b] = (uint8_t) (v >> (8 * b));
+            }
+            else { // wider values are fetched from the record
+                const uint8_t *src = p.blob + grp_offset(p, (uint64_t) i + 1) - p.vbytes;
+                reinterpret_cast<GrpU64 *>(dst)->v = v;
+                uint32_t b = 8;
+                for (; b + 8 <= p.vbytes; b += 8)
+                    reinterpret_cast<GrpU64 *>(dst + b)->v = reinterpret_cast<const GrpU64 *>(src + b)->v;
+                for (; b < p.vbytes; b++) dst[b] = src[b];
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) p.group_start[p.tile_count[p.ntiles]] = p.n;

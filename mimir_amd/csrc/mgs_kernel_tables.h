@@ -22,6 +22,9 @@ struct OsVariant {
 // Variant 0 is what production calls run; the rest are there to be timed against it
 // (mgs_set_tuning, tools/tune_onesweep.py): each prices one design decision on the hardware.
 const OsVariant *os16_variants(int *count);
+// The production kernel with the destination taken from a bit field of a record's first word
+// (OSV_DIGIT): one pass of a stable radix sort of 16-byte records.
+const OsVariant *os16_digit_variant();
 
 // ---- byte-granular records, LDS staging (mgs_osv.hip) ------------------------------------
 // k: records per worker lane (1, 2, 4); lm: layout mode 0..2

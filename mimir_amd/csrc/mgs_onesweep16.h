@@ -50,6 +50,7 @@ constexpr int OSV_NO_PREFETCH = 8; // load a tile only once it is this workgroup
 constexpr int OSV_EARLY_AGG = 32;  // the last worker wave to finish hashing publishes the tile's counts
 constexpr int OSV_NODEST = 8192;     // experiment: no dest_out
 constexpr int OSV_STATS = 16;      // diagnostic: count polls / depth / cycles of the chained scan
+constexpr int OSV_DIGIT = 64;      // the destination is a bit field of a record's first word, not a hash (see OsParams::klen)
 
 struct OsParams {
     const uint4 *rec; // record 0 of this call
@@ -57,8 +58,8 @@ struct OsParams {
     uint64_t first;   // absolute index of record 0 (for the result only)
     uint32_t P;
     int32_t self;
-    uint32_t klen;  // key bytes (1..16)
-    uint32_t kmask[4]; // per key word: mask of the bytes that belong to the key
+    uint32_t klen;  // key bytes (1..16); OSV_DIGIT kernels: the shift of the bit field that is the destination
+    uint32_t kmask[4]; // per key word: mask of the bytes that belong to the key; OSV_DIGIT: [0] = mask of that field
     uint32_t nbits; // ceil(log2(P)), >= 1
     uint32_t nbits_pad; // ceil(log2(P)), >= 0: lanes per predecessor in the chained scan = 1 << nbits_pad
     FastMod fm;

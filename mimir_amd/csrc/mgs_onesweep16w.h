@@ -297,6 +297,32 @@ __device__ __forceinline__ void os_hash_rows(const OsParams &p, const uint4 (&r)
     }
 }
 
+// The same for kernels built with OSV_DIGIT: a record's destination is the bit field
+// (word 0 >> p.klen) & p.kmask[0].  With the partitions laid end to end in the order of the
+// field's values -- part_base from a histogram -- one launch is one pass of a stable
+// least-significant-digit radix sort of 16-byte records whose first word is the sort key
+// (KV -> KMV, mgs_group.h).
+template <int ITEMS, int NB>
+__device__ __forceinline__ void os_digit_rows(const OsParams &p, const uint4 (&r)[ITEMS], uint64_t idx0,
+                                              uint32_t *wave_counts, uint32_t (&meta)[ITEMS])
+{
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const bool valid = idx0 + (uint32_t) k * 64 < p.n;
+        const uint32_t d = (r[k].x >> p.klen) & p.kmask[0];
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (uint32_t bit = 0; bit < (uint32_t) NB; bit++) {
+            const bool one = (d >> bit) & 1u;
+            const uint64_t bk = __ballot(one);
+            m &= one ? bk : ~bk;
+        }
+        const uint32_t rank = lanes_below(m);
+        const uint32_t cnt = (uint32_t) __popcll(m);
+        if (valid && rank == 0) atomicAdd(&wave_counts[d], cnt);
+        meta[k] = d | (rank << 8) | (cnt << 16) | (valid ? 0x80000000u : 0u);
+    }
+}
 
 // ---- rounds ------------------------------------------------------------------------
 // A round (src/collectiveshuffler.h:148-160) ends before the first record that does
@@ -694,7 +720,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
         uint32_t *wc = wcnt + par * CNT;
         uint32_t meta[ITEMS]; // dest | rank<<8 | count<<16 | valid<<31
         const uint64_t idx0 = (uint64_t) tile * TILE + (uint32_t) w * (ITEMS * 64) + lane;
-        if (p.fm.pow2) {
+        if (VAR & OSV_DIGIT) {
+            os_digit_rows<ITEMS, NB>(p, r, idx0, wc + w * OS_MAXP, meta);
+        }
+        else if (p.fm.pow2) {
             if (p.klen > 12) os_hash_rows<ITEMS, NB, true, true>(p, r, idx0, wc + w * OS_MAXP, meta);
             else os_hash_rows<ITEMS, NB, true, false>(p, r, idx0, wc + w * OS_MAXP, meta);
         }

@@ -28,7 +28,11 @@ static const OsVariant kOsVariants[] = {
     OSV("t512x8-fakechain", 512, 8, OSV_FAKE_CHAIN, 2),
     OSV("t512x8-stats", 512, 8, OSV_STATS, 2),              // 10
 };
+// one pass of a radix sort of 16-byte records (OSV_DIGIT): not a pack kernel, so not in the list above
+static const OsVariant kOsDigit = OSQ("q512x8-w8-digit", 512, 8, OSV_EARLY_AGG | OSV_DIGIT, 2, 8);
 } // namespace
+
+const OsVariant *os16_digit_variant() { return &kOsDigit; }
 
 const OsVariant *os16_variants(int *count)
 {

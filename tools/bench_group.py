@@ -2,7 +2,7 @@
 """Device time of mgs_group_device (KV -> KMV: KMVContainer::convert) on resident
 records.  Algorithmic bytes = the records read once + the values, one
 group_first and one group_start entry per group written.
-Usage: python tools/bench_group.py [records] [rounds]"""
+Usage: python tools/bench_group.py [records] [rounds] [words|u64]"""
 import json
 import os
 import sys
@@ -21,9 +21,13 @@ from mimir_amd.packer import DevicePacker, group_records  # noqa: E402
 def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 60_000_000
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    for name, (blob, offs, lay_t) in (
-            ("words Zipf(1.0) over 1e6, len 6+-1", datagen.word_records(n, 1_000_000, 1.0, 6, 1.0, seed=44)),
-            ("u64/u64, all keys distinct", datagen.u64_records(n, seed=42))):
+    only = sys.argv[3] if len(sys.argv) > 3 else ""
+    cases = []
+    if only in ("", "words"):
+        cases.append(("words Zipf(1.0) over 1e6, len 6+-1", datagen.word_records(n, 1_000_000, 1.0, 6, 1.0, seed=44)))
+    if only in ("", "u64"):
+        cases.append(("u64/u64, all keys distinct", datagen.u64_records(n, seed=42)))
+    for name, (blob, offs, lay_t) in cases:
         lay = capi.Layout.make(*lay_t)
         pk = DevicePacker(lay, 2, -1, 4096, 1)
         d = torch.from_numpy(blob).cuda()
