@@ -77,6 +77,25 @@ def test_group_other_layouts(oracle):
     check(oracle, blob, offs, (capi.KEY_CSTR, 0, capi.VAL_VOID, 0), len(keys))
 
 
+@pytest.mark.parametrize("vbytes", [1, 4, 7, 8, 9, 12, 24])
+def test_group_value_widths(oracle, vbytes):
+    """Values narrower than, equal to and wider than the 8 bytes that travel inside the sort
+    records (wider ones fetch their tail from the record), behind string keys of 1..20 bytes:
+    keys longer than 8 bytes share their first 8 bytes with others (the slot's copy of a key's
+    first bytes decides nothing then, the stream does)."""
+    n = 120_000
+    rng = np.random.default_rng(vbytes)
+    stems = [b"k", b"abcdefg", b"abcdefgh", b"abcdefghi", b"abcdefghijklmnopqrs", b"abcdefghX", b"abcdefgh1", b"zz"]
+    keys = [stems[int(j)] + bytes([97 + int(t)]) * int(r) + b"\0"
+            for j, t, r in zip(rng.integers(0, len(stems), n), rng.integers(0, 3, n), rng.integers(0, 2, n))]
+    vals = rng.integers(0, 256, size=(n, vbytes), dtype=np.uint8)
+    recs = [k + v.tobytes() for k, v in zip(keys, vals)]
+    blob = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    groups, _ = check(oracle, blob, offs, (capi.KEY_CSTR, 0, capi.VAL_FIXED, vbytes), n, page_bytes=1 << 16)
+    assert groups == len(set(keys))
+
+
 def test_group_keys_that_share_a_prefix_and_a_hash_slot(oracle):
     """Keys differing only in length or in the last byte, many of them colliding in the table."""
     n = 100000
