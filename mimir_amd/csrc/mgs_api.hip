@@ -129,6 +129,8 @@ struct mgs_handle {
     size_t rt_words = 0, rtab_words = 0;
     uint32_t pending_rounds = 0; // > 0: the call in flight leaves a result table for that many rounds
     bool pending_streams = false; // ... in the streams layout (rounds are views into destination streams)
+    uint16_t *d_seg = nullptr; // streams layout, 16-byte records: units per (tile, worker wave, destination)
+    size_t seg_bytes = 0;
     uint8_t *d_round_image = nullptr; // streams layout packed round by round: the send image of one round
     uint8_t *d_unp = nullptr;   // receive-side scratch (chunk and piece tables, cuts, result)
     size_t unp_bytes = 0;
@@ -288,6 +290,7 @@ void mgs_destroy(mgs_handle *h)
         if (h->d_rtab) (void) hipFree(h->d_rtab);
         if (h->h_rtab) (void) hipHostFree(h->h_rtab);
         if (h->d_round_image) (void) hipFree(h->d_round_image);
+        if (h->d_seg) (void) hipFree(h->d_seg);
         if (h->d_unp) (void) hipFree(h->d_unp);
         if (h->d_grp) (void) hipFree(h->d_grp);
         if (h->h_unp) (void) hipHostFree(h->h_unp);
@@ -743,6 +746,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         p.f_max_rounds = 0;
         p.f_cap = 0;
         p.f_rt = p.f_rt_start = p.clip_out = nullptr;
+        p.seg = nullptr;
         MGS_HIP(h, hipMemsetAsync(d_status, 0, (size_t) p.ntiles * P * sizeof(unsigned long long), stream));
         if (V.agg16)
             MGS_HIP(h, hipMemsetAsync(d_agg16, 0, ((size_t) p.ntiles << p.lpt_log) * sizeof(unsigned long long), stream));
@@ -769,6 +773,20 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             p.finder = 1;
             p.f_max_rounds = max_rounds;
             p.f_cap = (unsigned long long) (D.buf_size >> 4);
+            // the sweep's units per (tile, worker wave, destination): the finder hashes only the
+            // 512 records around a cut again
+            {
+                const size_t seg_bytes = (size_t) p.ntiles * (size_t) (V.threads / 64 - 1) * (size_t) P * sizeof(uint16_t);
+                if (h->seg_bytes < seg_bytes) {
+                    if (h->d_seg) MGS_HIP(h, hipFree(h->d_seg));
+                    h->d_seg = nullptr;
+                    h->seg_bytes = 0;
+                    MGS_HIP(h, hipMalloc(&h->d_seg, seg_bytes));
+                    h->seg_bytes = seg_bytes;
+                }
+                p.seg = h->d_seg;
+                MGS_HIP(h, hipMemsetAsync(h->d_seg, 0xFF, seg_bytes, stream));
+            }
             d_tab = h->d_rtab;
             MGS_HIP(h, hipMemsetAsync(h->d_rt, 0, round_table_words(max_rounds, P, true) * sizeof(unsigned long long), stream));
             grid = std::min<uint32_t>(p.ntiles, (uint32_t) (h->num_cus * V.blocks_per_cu) - 1u) + 1u;

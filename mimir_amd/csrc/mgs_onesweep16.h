@@ -95,6 +95,11 @@ struct OsParams {
     // optional, written by the kernel that finishes a one-round call: [0] = records of this
     // call that were packed, [1 + c] = units of column c before the first record that was not
     unsigned long long *clip_out;
+    // Streams layout, 16-byte records: units per (tile, worker wave, column) as 16-bit counts,
+    // [ntiles][worker waves][P], 0xFFFF = not written yet.  A worker wave's records are 512
+    // consecutive ones, so with these the round finder narrows a cut to one such segment and
+    // hashes only that again instead of the whole tile.  NULL: not kept.
+    uint16_t *seg;
 };
 
 constexpr unsigned long long OS_RT_VALID = 1ull << 63;

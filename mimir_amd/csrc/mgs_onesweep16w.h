@@ -532,7 +532,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
         typedef FinderLdsT<TILE / 64> FL;
         static_assert(sizeof(FL) <= sizeof(srec), "the finder's tables live in the tile image");
         FinderSrc16 src{p};
-        os_round_finder<FinderSrc16, THREADS / 64, TILE / 64>(p, P, src, reinterpret_cast<FL *>(srec), tid);
+        os_round_finder<FinderSrc16, THREADS / 64, TILE / 64, ITEMS>(p, P, src, reinterpret_cast<FL *>(srec), tid);
         return;
     }
 
@@ -583,6 +583,15 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
             const uint32_t first_slot = wave_incl_scan_u32(tot, lane) - tot;
             __syncthreads(); // B
             const uint32_t next = misc[1];
+            // for the round finder: the units per (worker wave, column) -- a worker wave's records
+            // are 512 consecutive ones.  Stored before the look-back, so that they are out when the
+            // tile's prefix is (the finder waits for them otherwise); the counts stay in LDS until
+            // this wave clears them one tile later
+            if (p.seg && (uint32_t) lane < P) {
+#pragma unroll
+                for (int ww = 0; ww < WORKERS; ww++)
+                    p.seg[((uint64_t) tile * WORKERS + ww) * P + lane] = (uint16_t) wc[ww * OS_MAXP + lane];
+            }
             if (tile != 0) {
                 if (VAR & OSV_FAKE_CHAIN) acc = (unsigned long long) tile * (TILE / P);
                 else acc = os_window_walk<VAR, LOOK>(p, tile, lane, &ws);
@@ -786,7 +795,6 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweep16q(OsParams p)
         if (prev != 0xFFFFFFFFu) store_image(prev, par ^ 1);
         __syncthreads(); // B: every slot of image(prev) has been read, the image is free
         const uint32_t next = misc[1];
-
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             const uint32_t d = meta[k] & 0xffu, rank = (meta[k] >> 8) & 0xffu;
