@@ -917,8 +917,6 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             // layout mode 1: ONE string key and a fixed-width or absent value
             const int lm = (L.val_kind == MGS_VAL_CSTR) ? 0 : (L.key_kind == MGS_KEY_CSTR ? (L.key_count == 1 ? 1 : 0) : 2);
             if (legacy) {
-                if (check_spans && !use_osr)
-                    hipLaunchKernelGGL(k_osv_check, dim3((c.ntiles + 255) / 256), dim3(256), 0, stream, q);
                 MGS_HIP(h, hipEventRecord(h->ev0, stream));
                 if (use_osr) {
                     q.in_bytes = (uint32_t) osr_image_bytes(osr_nq);

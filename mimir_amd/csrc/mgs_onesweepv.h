@@ -36,10 +36,9 @@
 //             tile records its index (round cut), k_osv_finalize re-walks that
 //             one tile.
 //
-// The kernel needs every tile's span to fit the LDS staging buffer.  For
-// variable-width input k_osv_check tests that on the device first and raises
-// Ctrl::head.fallback otherwise; the one-sweep kernels then return at once and
-// the generic path, enqueued behind them, does the work.
+// The kernel needs every tile's span to fit the LDS staging buffer.  It tests that tile
+// by tile (sanitize): a tile that does not fit is treated as empty and Ctrl::head.fallback is
+// raised; the host then redoes the call with the generic kernels (mgs_pack_result).
 #ifndef MGS_ONESWEEPV_H
 #define MGS_ONESWEEPV_H
 
@@ -172,21 +171,6 @@ __device__ __forceinline__ void ov_raw_barrier()
     asm volatile("s_barrier" ::: "memory");
 }
 
-// Does every tile's span fit the staging buffer?  One thread per tile.
-#ifndef MGS_TEMPLATES_ONLY // a translation unit that only instantiates kernel templates skips the plain kernels
-__global__ void k_osv_check(OvParams q)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= q.os.ntiles) return;
-    const uint64_t T = q.os.tile_records;
-    const uint64_t i0 = (uint64_t) t * T, i1 = min(q.n, i0 + T);
-    const uint64_t s = ov_offset(q, i0), e = ov_offset(q, i1);
-    const uint64_t shift = ((uintptr_t) q.blob + s) & 15u;
-    if (e < s || e - s + shift > (uint64_t) q.in_bytes)
-        __hip_atomic_store(&q.os.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-#endif
-
 // The round finder's view of a tile of byte-granular records (mgs_round_finder.h): the
 // tile's span is parked in the staging buffer, key lengths and hashes are read from there.
 struct FinderSrcV {
@@ -204,7 +188,7 @@ struct FinderSrcV {
         const uintptr_t a0 = ((uintptr_t) q.blob + s) & ~(uintptr_t) 15;
         shift = (uint32_t) (((uintptr_t) q.blob + s) & 15u);
         span = (e >= s ? e - s : 0) + shift;
-        if (span > (uint64_t) q.in_bytes) span = 0; // k_osv_check has sent such a call to the generic path
+        if (span > (uint64_t) q.in_bytes) span = 0; // (the sweep sends such a call to the generic path)
         const uint32_t nch = (uint32_t) ((span + 15) >> 4);
         __syncthreads(); // the previous tile's bytes are no longer read
         for (uint32_t ch = (uint32_t) tid; ch < nch; ch += (uint32_t) nthreads)
@@ -451,6 +435,22 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
                 f.rec[k] = (uint32_t) (min(i1, i0 + (uint64_t) wt * K + k) - i0) * q.fixed_len;
         }
     };
+    // The tile's span must fit the staging buffer and lie inside the call's bytes.  One that
+    // does not -- records too long for this kernel, or offsets that are not monotonic -- is
+    // treated as empty (nothing of it is loaded) and Ctrl::head.fallback is raised: the host
+    // then redoes the call with the kernels that take any record.
+    const uint64_t blob_end = ov_offset(q, q.n);
+    auto sanitize = [&](Offsets &f) {
+        const uint32_t shift = (uint32_t) (((uintptr_t) q.blob + f.base + f.s) & 15u);
+        const bool fits = f.e >= f.s && (uint64_t) (f.e - f.s) + shift <= (uint64_t) INB && f.base + f.e <= blob_end;
+        if (!fits) {
+            __hip_atomic_store(&p.ctrl->head.fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f.s = f.e = 0;
+            f.nrec = 0;
+#pragma unroll
+            for (int k = 0; k <= K; k++) f.rec[k] = 0;
+        }
+    };
     // Issue the 16-byte loads of the span [s, e) (aligned down to 16 bytes).
     auto fetch_chunks = [&](uint64_t s, uint64_t e, uint4 (&ch)[CPT]) {
         const uintptr_t a0 = ((uintptr_t) q.blob + s) & ~(uintptr_t) 15;
@@ -558,6 +558,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
         if (tile < p.ntiles) {
             fetch_offsets(tile, f0);
             if (next < p.ntiles) fetch_offsets(next, fn);
+            sanitize(f0);
             fetch_chunks(f0.base + f0.s, f0.base + f0.e, ch);
             park_chunks(f0.base + f0.s, f0.base + f0.e, ch);
             set_records(f0);
@@ -718,7 +719,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepv(OvParams q)
         // bytes of the next tile (its offsets arrived during the last trip): in flight
         // during the store and the reorder
         uint4 ch[CPT];
-        if (next < p.ntiles) fetch_chunks(fn.base + fn.s, fn.base + fn.e, ch);
+        if (next < p.ntiles) {
+            sanitize(fn);
+            fetch_chunks(fn.base + fn.s, fn.base + fn.e, ch);
+        }
         if (have_prev) store_image(par ^ 1, false);
         OV_PHASE(3)
         __syncthreads(); // B: the image is free
