@@ -1,5 +1,5 @@
 // src/gpushuffler.h -- the file a Mimir maintainer adds to bind the GPU pack path
-// (this repository: integration/gpushuffler.h; shown verbatim in INTEGRATION.md).
+// (this repository: integration/gpushuffler.h; the integration document shows it verbatim).
 // Syntax-checked against the reference's own headers by tests/test_integration_binding.py.
 #include <mpi.h>
 #include "config.h"                    // COMM_BUF_SIZE

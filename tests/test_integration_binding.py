@@ -1,4 +1,4 @@
-"""The Mimir-side binding of INTEGRATION.md (integration/gpushuffler.h) must be
+"""The Mimir-side binding (integration/gpushuffler.h, shown in the integration document) must be
 real code: it is compiled, syntax only, against the reference's own headers
 (src/baseshuffler.h:27-35, :255-265; src/interface.h:18-86), instantiated for the
 record types of the examples, and the document must show the same text."""
@@ -60,7 +60,7 @@ def test_document_shows_the_binding_file():
     with open(BINDING) as f:
         code = f.read()
     with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
-        assert code in f.read(), "INTEGRATION.md and integration/gpushuffler.h differ"
+        assert code in f.read(), "the integration document and integration/gpushuffler.h differ"
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_SRC) or not os.path.exists(os.path.join(MPI_INC, "mpi.h")),
