@@ -153,6 +153,8 @@ struct mgs_handle {
     double ov_bytes_per_record = 16.0; // variable width: average record length seen last
     int ov_shrink = 0;        // ... and how much smaller than that length suggests the tile must be
     bool pending_osr = false; // the call in flight runs k_onesweepr
+    int pending_osr_nq = 0;   // ... with that many register quads per record (3: a quad and a dword)
+    bool osr_q3_off = false;  // string keys: too many records of this handle are longer than a quad and a dword
     const char *last_kernel = "none";
     int pending_ov_k = 4;
     // call in flight
@@ -477,18 +479,20 @@ static bool osr_enabled(const mgs_handle *h)
 // width: 1.25 times the average seen).  The order is the order of preference measured on
 // MI355X: fixed widths above 16 bytes and string keys with few records per lane run fastest
 // with three records per lane and early requests, string keys otherwise with four.
-static bool osr_pick(int lm, bool a4, double bytes_per_record, int shrink, int *k_out, int *nq_out)
+// (nq = 3 stands for a quad and a dword: records of up to 20 bytes, allowed with q3)
+static bool osr_pick(int lm, bool a4, double bytes_per_record, int shrink, int *k_out, int *nq_out, bool q3 = false)
 {
     static const int fixed_order[3][2] = {{4, 1}, {3, 2}, {4, 2}};
-    static const int cstr_order[4][2] = {{4, 2}, {3, 2}, {2, 2}, {1, 2}};
+    static const int cstr_order[5][2] = {{4, 3}, {4, 2}, {3, 2}, {2, 2}, {1, 2}};
     const int(*cand)[2] = lm == 2 ? fixed_order : cstr_order;
-    const int ncand = lm == 2 ? 3 : 4;
+    const int ncand = lm == 2 ? 3 : 5;
     int skipped = 0;
     for (int i = 0; i < ncand; i++) {
         const int k = cand[i][0], nq = cand[i][1];
         if (!osr_has(k, nq, lm, a4)) continue;
         if ((double) (kOvLanes * k) * bytes_per_record > (double) osr_image_bytes(nq)) continue;
         if (nq == 1 && bytes_per_record > 16.0) continue;
+        if (nq == 3 && (!q3 || bytes_per_record > 20.0)) continue;
         if (skipped++ < shrink) continue; // a tile of this size did not fit last time
         *k_out = k;
         *nq_out = nq;
@@ -496,9 +500,12 @@ static bool osr_pick(int lm, bool a4, double bytes_per_record, int shrink, int *
     }
     return false;
 }
-// String keys: below this average record length the staged kernel (k_onesweepv) is the faster one
-// (measured: 15-byte wordcount records 0.34 against 0.31 of HBM, 22-byte join records 0.36 against 0.40).
+// String keys: below this average record length the register kernel with two quads per record loses to
+// the staged kernel (k_onesweepv; measured: 15-byte wordcount records 0.28 against 0.35 of HBM, 22-byte
+// join records 0.41 against 0.36).  Records of up to 16 bytes on average take the register kernel that
+// holds a quad and a dword (0.357 against 0.348) as long as few of them are longer than that.
 constexpr double kOsrMinCstrBytes = 18.0;
+constexpr double kOsrQ3MaxBytes = 16.0;
 
 // Enqueue one pack call.  noalloc: the control block and the chained-scan arrays live
 // in the device's static scratch array, nothing is allocated, only the one-sweep
@@ -645,8 +652,9 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
         }
         else {
             static const char *force = getenv("MGS_OSR_FORCE"); // experiments: whatever the record length
-            use_osr = (h->ov_bytes_per_record >= kOsrMinCstrBytes || (force && atoi(force)))
-                      && osr_pick(ov_lm, false, 1.25 * h->ov_bytes_per_record, h->ov_shrink, &osr_k, &osr_nq);
+            const bool q3 = !h->osr_q3_off && h->ov_bytes_per_record <= kOsrQ3MaxBytes;
+            use_osr = (h->ov_bytes_per_record >= kOsrMinCstrBytes || q3 || (force && atoi(force)))
+                      && osr_pick(ov_lm, false, 1.25 * h->ov_bytes_per_record, h->ov_shrink, &osr_k, &osr_nq, q3);
         }
         if (use_osr) {
             // experiments: pin the instantiation (records per lane, register quads)
@@ -998,6 +1006,7 @@ static int pack_enqueue(mgs_handle *h, const void *d_records, const uint32_t *d_
             }
             h->pending_ov_k = ov_k;
             h->pending_osr = legacy && use_osr;
+            h->pending_osr_nq = osr_nq;
             h->last_algo = legacy ? "onesweepv" : "onesweepd";
             h->last_kernel = legacy ? (use_osr ? "k_onesweepr" : "k_onesweepv") : "k_onesweepd";
         }
@@ -1146,6 +1155,11 @@ static int pack_result_impl(mgs_handle *h, mgs_round *out, bool rounds_caller)
         for (int b = 0; b < P; b++) bytes += out->send_offset[b] - h->pending_init[b];
         if (recs > 0 && bytes > 0 && h->pending_rounds <= 1 && !h->pending_streams) h->ov_bytes_per_record = (double) bytes / (double) recs;
         if (h->pending_osv) h->ov_shrink = 0; // a one-sweep kernel served the call: the length alone decides again
+        // records longer than a quad and a dword took the slow way round: more than one in 64 and the
+        // handle goes back to the kernels that hold whole records
+        const uint64_t recs_call = h->pending_rounds ? (uint64_t) h->h_rtab[1] - h->pending_start : recs;
+        if (h->pending_osr && h->pending_osr_nq == 3 && (uint64_t) h->h_ctrl->head.long_records * 64u > recs_call)
+            h->osr_q3_off = true;
 
     }
     return MGS_OK;

@@ -137,14 +137,18 @@ __device__ __forceinline__ uint32_t osr_hash_key16(const uint32_t (&w)[4], uint3
 // aligned dwords; IMG: bytes of the LDS image; PRE: the first quads of the next tile are
 // requested before the store of the previous tile (16 more registers per 4 records) instead
 // of at the end of the trip.
-template <int THREADS, int K, int NQ, int VAR, int MINW, int LOOK, int LM, bool A4, int IMG, bool PRE>
+// Q1W: dwords of a record's bytes from 16 on that are held (NQ = 2): 4, or 1 for records of at
+// most 20 bytes (wordcount: a word, its NUL and eight value bytes) -- fewer registers, which
+// pays for requesting the next tile's first quads a phase early (PRE).
+template <int THREADS, int K, int NQ, int VAR, int MINW, int LOOK, int LM, bool A4, int IMG, bool PRE, int Q1W = 4>
 __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
 {
     static_assert(LM == 1 || LM == 2, "layout modes 1 and 2");
     static_assert(!A4 || LM == 2, "dword moves need fixed widths");
     const OsParams &p = q.os;
     constexpr int WORKERS = THREADS / 64 - 1, WT = WORKERS * 64, T = WT * K;
-    constexpr uint32_t RB = 16u * NQ; // bytes of a record held in registers
+    static_assert(Q1W == 4 || Q1W == 1, "the second part of a record is a quad or a dword");
+    constexpr uint32_t RB = NQ > 1 ? 16u + 4u * Q1W : 16u; // bytes of a record held in registers
     __shared__ __attribute__((aligned(16))) uint8_t sout[IMG + 32]; // reads run up to 19 bytes past a run
     __shared__ uint32_t wcnt[2 * WORKERS * OS_MAXP];                // bytes per (wave, dest), two tiles
     __shared__ uint32_t wslot[WORKERS * OS_MAXP];                   // first image byte of (wave, dest)
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
     uint32_t len[K];              // record k: length (0 = no record)
     uint32_t roff[K];             // its first byte, relative to cur_base
     uint32_t q0[K][4];            // its bytes 0..15
-    uint32_t q1[K][4];            // its bytes 16..31 (NQ = 2), requested at the end of the trip before its own
+    uint32_t q1[K][Q1W];          // its bytes from 16 on (NQ = 2), requested at the end of the trip before its own
     uint64_t cur_base = 0;        // byte of blob the current tile's offsets are relative to
     uint32_t cur_lim = 0;         // bytes from cur_base to the end of the call's records (clamped)
     uint32_t cur_end = 0;         // the current tile's last byte + 1, from cur_base
@@ -447,33 +451,39 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         }
     };
     // Bytes 16..31 of the records that have them (after settle: the lengths are known).
-    auto load_q1 = [&](uint32_t (&t)[K][4]) {
+    auto load_q1 = [&](uint32_t (&t)[K][Q1W]) {
         const uint8_t *tb = q.blob + cur_base;
+        constexpr uint32_t LB = 4u * Q1W; // bytes of one load
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const uint8_t *src = cur_lim >= 16u ? tb + min(roff[k] + 16u, cur_lim - 16u) // (clamped: see issue_q0)
-                                                : reinterpret_cast<const uint8_t *>(p.ctrl);
-            const OvU128 v = *reinterpret_cast<const OvU128 *>(src);
-            t[k][0] = v.x;
-            t[k][1] = v.y;
-            t[k][2] = v.z;
-            t[k][3] = v.w;
+            const uint8_t *src = cur_lim >= LB ? tb + min(roff[k] + 16u, cur_lim - LB) // (clamped: see issue_q0)
+                                               : reinterpret_cast<const uint8_t *>(p.ctrl);
+            if (Q1W == 4) {
+                const OvU128 v = *reinterpret_cast<const OvU128 *>(src);
+                t[k][0] = v.x;
+                t[k][1 % Q1W] = v.y;
+                t[k][2 % Q1W] = v.z;
+                t[k][3 % Q1W] = v.w;
+            }
+            else {
+                t[k][0] = reinterpret_cast<const OvU32 *>(src)->v;
+            }
         }
         if (__any(cur_end + 16u > cur_lim)) { // the tile ends next to the end of the call
             uint32_t bytewise = 0;
 #pragma unroll
             for (int k = 0; k < K; k++)
-                if (len[k] > 16u && !quad_ok(roff[k] + 16u, cur_lim)) bytewise |= 1u << k;
+                if (len[k] > 16u && roff[k] + 16u + LB > cur_lim) bytewise |= 1u << k;
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 if (!((bytewise >> k) & 1u)) continue;
                 const uint32_t l = pick(len, k) - 16u;
                 uint32_t b16[4];
-                bytewise16(tb + pick(roff, k) + 16u, l < 16u ? l : 16u, b16);
+                bytewise16(tb + pick(roff, k) + 16u, l < LB ? l : LB, b16);
 #pragma unroll
                 for (int kk = 0; kk < K; kk++) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < Q1W; j++)
                         if (kk == k) t[kk][j] = b16[j];
                 }
             }
@@ -576,7 +586,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         len[k] = 0;
         roff[k] = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) q0[k][j] = q1[k][j] = 0;
+        for (int j = 0; j < 4; j++) q0[k][j] = 0;
+#pragma unroll
+        for (int j = 0; j < Q1W; j++) q1[k][j] = 0;
     }
     if (tile < p.ntiles) {
         Offsets f0;
@@ -789,7 +801,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
                     for (int k = 0; k < K; k++) {
                         uint32_t *o = reinterpret_cast<uint32_t *>(sout + dst[k]);
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
+                        for (int j = 0; j < Q1W; j++)
                             if ((uint32_t) (16 + 4 * j) < len[k]) o[4 + j] = q1[k][j];
                     }
                 }
@@ -804,7 +816,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
 #pragma unroll
                     for (int k = 0; k < K; k++) {
                         if (len[k] <= 16) continue;
-                        put(sout + dst[k] + 16, q1[k][0], q1[k][1], q1[k][2], q1[k][3], len[k] - 16);
+                        const uint32_t n1 = len[k] - 16u < 4u * Q1W ? len[k] - 16u : 4u * Q1W; // (the rest: below)
+                        put(sout + dst[k] + 16, q1[k][0], q1[k][1 % Q1W], q1[k][2 % Q1W], q1[k][3 % Q1W], n1);
                     }
                 }
             }

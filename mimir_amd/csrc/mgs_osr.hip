@@ -13,18 +13,20 @@ struct OsrEntry {
     int var; // OSV_* bits of the instantiation (0: production)
     OsrKernel fn;
 };
-#define OSR(K, NQ, LM, A4, PRE, V) \
-    {K, NQ, LM, A4, PRE, V, k_onesweepr<OSR_THREADS, K, NQ, V, 4, 8, LM, A4, (NQ == 1 ? OSR_IMG1 : OSR_IMG2), PRE>}
+// NQ: 16-byte register quads per record; 3 stands for a quad and a dword (records up to 20 bytes)
+#define OSR(K, NQ, LM, A4, PRE, V)                                                                                   \
+    {K, NQ, LM, A4, PRE, V,                                                                                          \
+     k_onesweepr<OSR_THREADS, K, (NQ == 3 ? 2 : NQ), V, 4, 8, LM, A4, (NQ == 1 ? OSR_IMG1 : OSR_IMG2), PRE, (NQ == 3 ? 1 : 4)>}
 const OsrEntry kOsr[] = {
     // one string key + fixed-width or absent value
     OSR(4, 2, 1, false, false, 0), OSR(3, 2, 1, false, true, 0), OSR(3, 2, 1, false, false, 0), OSR(2, 2, 1, false, true, 0),
-    OSR(1, 2, 1, false, true, 0),
+    OSR(1, 2, 1, false, true, 0), OSR(4, 3, 1, false, false, 0), OSR(4, 3, 1, false, true, 0),
     // fixed widths up to 16 / 32 bytes; multiples of four bytes move as dwords
     OSR(4, 1, 2, false, true, 0), OSR(4, 2, 2, false, false, 0), OSR(3, 2, 2, false, true, 0),
     OSR(4, 1, 2, true, true, 0), OSR(4, 2, 2, true, false, 0), OSR(3, 2, 2, true, true, 0),
     // diagnostic builds: cycles per phase
     OSR(4, 2, 1, false, false, OSV_STATS), OSR(3, 2, 1, false, true, OSV_STATS), OSR(4, 2, 2, true, false, OSV_STATS),
-    OSR(4, 1, 2, true, true, OSV_STATS),
+    OSR(4, 1, 2, true, true, OSV_STATS), OSR(4, 3, 1, false, true, OSV_STATS),
     OSR(4, 2, 1, false, false, OSV_STATS | OSV_NO_PREFETCH), OSR(4, 2, 1, false, false, OSV_STATS | OSV_FAKE_CHAIN),
     // timing only (wrong output): no chained scan, positions are made up -- prices the chain
     OSR(4, 2, 1, false, false, OSV_FAKE_CHAIN), OSR(3, 2, 1, false, true, OSV_FAKE_CHAIN), OSR(4, 2, 2, true, false, OSV_FAKE_CHAIN),

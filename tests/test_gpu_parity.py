@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle:
 same destination for every record, byte-identical partitions in stable emit
 order, same round boundaries.  Bit-exact: this is integer/byte work."""
+import os
+
 import numpy as np
 import pytest
 
@@ -406,6 +408,42 @@ def test_onesweepv_adapts_tile_to_record_length(oracle):
         assert np.array_equal(local.cpu().numpy()[:got.local_bytes], want["local"])
     assert algos[0] == "generic" and algos[1] == "onesweepv" and algos[2] == "onesweepv", algos
     pk.close()
+
+
+def test_short_string_records_take_the_quad_and_dword_kernel_until_long_ones_show(oracle):
+    """Wordcount-sized records (16 bytes or less on average) run the register kernel that holds 20
+    bytes of a record; records longer than that are copied the slow way and counted, and once more
+    than one in 64 is that long the handle goes back to the staged kernel.  Same bytes either way."""
+    torch = _torch()
+    from mimir_amd.packer import DevicePacker
+    n, P = 200_000, 8
+    for share, expect_second in ((0.0, "k_onesweepr"), (0.06, "k_onesweepv")):
+        rng = np.random.default_rng(int(share * 100) + 3)
+        lens = np.where(rng.random(n) < share, rng.integers(13, 40, n), rng.integers(4, 8, n))
+        words = [bytes(rng.integers(97, 123, size=int(l), dtype=np.uint8)) + b"\0" + int(i).to_bytes(8, "little")
+                 for i, l in enumerate(lens)]
+        blob = np.frombuffer(b"".join(words), dtype=np.uint8)
+        offs = np.concatenate([[0], np.cumsum([len(w) for w in words])]).astype(np.uint64)
+        lay = (capi.KEY_CSTR, 0, capi.VAL_FIXED, 8)
+        glay, olay = _layouts(lay)
+        total = int(offs[-1])
+        want = oracle.pack_round(olay, blob, offs, n, 0, P, -1, total)
+        d_blob = torch.from_numpy(np.ascontiguousarray(blob)).cuda()
+        d_off = torch.from_numpy(offs.astype(np.uint32).view(np.int32)).cuda()
+        pk = DevicePacker(glay, P, -1, total, n)
+        kernels = []
+        for _ in range(2):
+            image = torch.full((P * total,), 0xEE, dtype=torch.uint8, device="cuda:0")
+            got = pk.pack(d_blob, n, image, rec_off=d_off)
+            kernels.append(pk.last_kernel())
+            assert got.next == n and got.send_offset.tolist() == want["send_offset"].tolist()
+            img = image.cpu().numpy()
+            for p in range(P):
+                so = int(want["send_offset"][p])
+                assert np.array_equal(img[p * total:p * total + so], want["partitions"][p]), (share, p)
+        if os.environ.get("MGS_OSR") != "0" and not os.environ.get("MGS_OSR_FORCE"):
+            assert kernels == ["k_onesweepr", expect_second], (share, kernels)
+        pk.close()
 
 
 def test_onesweepv_falls_back_on_long_records(oracle):
