@@ -548,10 +548,19 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
         }
         if (with_partials && w == WORKERS - 1) store_partials(pr);
     };
-    // n <= 16 bytes out of four registers to any address of the image
+    // n <= 16 bytes out of four registers to any address of the image.  Eight bytes and more go as
+    // two pieces that may overlap -- the first eight and the last eight -- instead of 8 + 4 + 2 + 1.
     auto put = [&](uint8_t *o, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t n) {
         if (n >= 16) {
             *reinterpret_cast<OvU128 *>(o) = OvU128{a0, a1, a2, a3};
+            return;
+        }
+        if (n >= 8) {
+            const unsigned long long lo = (unsigned long long) a0 | ((unsigned long long) a1 << 32);
+            const unsigned long long hi = (unsigned long long) a2 | ((unsigned long long) a3 << 32);
+            const uint32_t sh = 8u * (n - 8u); // 0 .. 56
+            reinterpret_cast<OvU64 *>(o)->v = lo;
+            reinterpret_cast<OvU64 *>(o + (n - 8u))->v = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
             return;
         }
         if (n & 8u) {
@@ -817,7 +826,17 @@ __global__ __launch_bounds__(THREADS, MINW) void k_onesweepr(OvParams q)
                     for (int k = 0; k < K; k++) {
                         if (len[k] <= 16) continue;
                         const uint32_t n1 = len[k] - 16u < 4u * Q1W ? len[k] - 16u : 4u * Q1W; // (the rest: below)
-                        put(sout + dst[k] + 16, q1[k][0], q1[k][1 % Q1W], q1[k][2 % Q1W], q1[k][3 % Q1W], n1);
+                        if (n1 < 8u) {
+                            // one piece: the eight bytes that end with byte 16 + n1 of the record
+                            const unsigned long long lo = (unsigned long long) q0[k][2] | ((unsigned long long) q0[k][3] << 32);
+                            const unsigned long long hi =
+                                (unsigned long long) q1[k][0] | ((unsigned long long) q1[k][1 % Q1W] << 32);
+                            const uint32_t sh = 8u * n1; // 8 .. 56
+                            reinterpret_cast<OvU64 *>(sout + dst[k] + 8u + n1)->v = (lo >> sh) | (hi << (64u - sh));
+                        }
+                        else {
+                            put(sout + dst[k] + 16, q1[k][0], q1[k][1 % Q1W], q1[k][2 % Q1W], q1[k][3 % Q1W], n1);
+                        }
                     }
                 }
             }
