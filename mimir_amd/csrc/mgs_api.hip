@@ -1606,9 +1606,12 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     p.nchunks = (uint32_t) ((nbytes + chunk - 1) / chunk);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t tables = (size_t) p.nchunks * UNP_PIECES * S;
-    const size_t need = up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t))
-                        + up(((size_t) p.nchunks + 1) * sizeof(uint64_t)) + up((size_t) p.nchunks * S * sizeof(uint32_t))
-                        + up((size_t) p.nchunks * sizeof(uint32_t))
+    p.nruns = (p.nchunks + UNP_RUN - 1) / UNP_RUN;
+    const size_t sync_bytes = up((2 + (size_t) p.nruns) * sizeof(uint32_t));
+    const size_t need = up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t)) + sync_bytes
+                        + up((size_t) p.nchunks * S * sizeof(uint32_t))
+                        + up((size_t) p.nruns * S * sizeof(uint32_t)) + up((size_t) p.nruns * S * sizeof(uint64_t))
+                        + up((size_t) p.nruns * sizeof(uint32_t)) + up((size_t) p.nruns * sizeof(uint64_t))
                         + up(tables * sizeof(uint16_t)) + up(tables)
                         + up((size_t) p.nchunks * (size_t) (p.chunk_bytes / 8));
     if (h->pending) { // the control block and the scratch are shared with the pack call in flight
@@ -1619,9 +1622,12 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     uint8_t *q = h->d_unp;
     p.result = reinterpret_cast<uint64_t *>(q); // result and cuts leave with one copy
     p.cuts = p.result + 2;                                    q += up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t));
-    p.first_rec = reinterpret_cast<uint64_t *>(q);            q += up(((size_t) p.nchunks + 1) * sizeof(uint64_t));
+    p.sync = reinterpret_cast<uint32_t *>(q);                 q += sync_bytes;
     p.table = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * S * sizeof(uint32_t));
-    p.entry = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * sizeof(uint32_t));
+    p.run_exit = reinterpret_cast<uint32_t *>(q);             q += up((size_t) p.nruns * S * sizeof(uint32_t));
+    p.run_count = reinterpret_cast<uint64_t *>(q);            q += up((size_t) p.nruns * S * sizeof(uint64_t));
+    p.run_entry = reinterpret_cast<uint32_t *>(q);            q += up((size_t) p.nruns * sizeof(uint32_t));
+    p.run_first = reinterpret_cast<uint64_t *>(q);            q += up((size_t) p.nruns * sizeof(uint64_t));
     p.piece_count = reinterpret_cast<uint16_t *>(q);          q += up(tables * sizeof(uint16_t));
     p.piece_exit = q;                                         q += up(tables);
     p.masks = reinterpret_cast<unsigned long long *>(q);      q += up((size_t) p.nchunks * (size_t) (p.chunk_bytes / 8));
@@ -1634,6 +1640,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
 
     MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
     MGS_HIP(h, hipMemsetAsync(p.result, 0, 2 * sizeof(uint64_t), stream));
+    if (nbytes && !fixed) MGS_HIP(h, hipMemsetAsync(p.sync, 0, sync_bytes, stream));
     if (nbytes == 0) {
         MGS_HIP(h, hipMemsetAsync(d_rec_off, 0, sizeof(uint32_t), stream));
     }
@@ -1650,7 +1657,6 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
         const size_t lds_spec = (2 * (size_t) S * 65 + 128) * sizeof(uint32_t);
         const size_t lds_emit = ((((size_t) UNP_PIECES * S + 128 + 3) & ~(size_t) 3) + 64 * UNP_SLOT_PITCH) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_unp_spec, dim3(p.nchunks), dim3(64), lds_spec, stream, p);
-        hipLaunchKernelGGL(k_unp_chain, dim3(1), dim3(64 * UNP_CHAIN_WAVES), 0, stream, p);
         hipLaunchKernelGGL(k_unp_emit, dim3(p.nchunks), dim3(64), lds_emit, stream, p);
     }
     hipLaunchKernelGGL(k_unp_pages, dim3(1), dim3(64), 0, stream, p);

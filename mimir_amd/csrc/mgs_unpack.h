@@ -24,12 +24,15 @@
 //                goes on with one parse.  The 64 piece tables (entry state ->
 //                exit state, records) are kept for k_unp_emit and composed into
 //                the chunk's table.
-//   k_unp_chain  one wave follows the chain through the chunks -> entry state
-//                and first record index of every chunk.
-//   k_unp_emit   the chunk's entry state is walked through the piece tables,
-//                then every lane parses its piece again from its true entry
-//                state and writes the record start offsets.
-//   k_unp_pages  one thread: greedy page cuts by binary search in the offsets.
+//                The chain through the chunks is cut into runs of 64 chunks: the
+//                workgroup that finishes a run last composes the run's table, and
+//                the one that finishes the last run follows state 0 through the
+//                run tables -> entry state and first record index of every run.
+//   k_unp_emit   follows its run's entry state through the chunks before its own,
+//                walks the chunk's entry state through the piece tables, then
+//                every lane parses its piece again from its true entry state and
+//                writes the record start offsets.
+//   k_unp_pages  one wave: greedy page cuts by a search in the offsets.
 //
 // Reading: per 64-byte step the wave fetches 64 rows (the lanes' current blocks)
 // as 16 rows x 64 contiguous bytes per load instruction, turns every 16 bytes
@@ -45,6 +48,7 @@ namespace mgs {
 constexpr int UNP_MAX_V = 62;        // value bytes handled: V + 2 entry states
 constexpr int UNP_MAX_CHUNKS = 4096; // one wave each: four per SIMD on a full device
 constexpr int UNP_PIECES = 64;       // pieces of a chunk, one lane each
+constexpr uint32_t UNP_RUN = 64;     // chunks whose tables are composed into one run table
 
 struct UnpParams {
     const uint8_t *stream;
@@ -58,8 +62,12 @@ struct UnpParams {
     uint16_t *piece_count; // [nchunks][64][V+2]
     unsigned long long *masks; // [nchunks][piece_bytes / 64][64]: NUL mask of every 64-byte block of every piece,
                                // left by k_unp_spec for k_unp_emit (an eighth of the stream, so that it is read once)
-    uint32_t *entry;      // [nchunks] entry state of each chunk
-    uint64_t *first_rec;  // [nchunks+1] index of the chunk's first record start (+ total)
+    uint32_t nruns;       // runs of UNP_RUN chunks
+    uint32_t *run_exit;   // [nruns][V+2] exit state of a run per entry state
+    uint64_t *run_count;  // [nruns][V+2] records of a run per entry state
+    uint32_t *run_entry;  // [nruns] entry state of each run
+    uint64_t *run_first;  // [nruns] index of the run's first record start
+    uint32_t *sync;       // zeroed per call: [0] runs composed, [2 + r] chunks of run r parsed
     uint32_t *rec_off;    // out: rec_off[i] = start of record i; rec_off[n] = nbytes
     uint64_t rec_cap;     // entries available in rec_off
     Ctrl *ctrl;
@@ -161,6 +169,107 @@ __device__ __forceinline__ uint32_t unp_step(uint64_t nul, uint32_t state, uint3
     return pos - valid;
 }
 
+// Words handed from one workgroup of a launch to another go past the caches of the compute
+// units' own die in both directions (unp_post, unp_peek), so no fence has to write a whole
+// cache back -- with hundreds of megabytes of masks on their way out that costs 0.2 ms a launch.
+template <class T>
+__device__ __forceinline__ void unp_post(T *ptr, T v)
+{
+    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <class T>
+__device__ __forceinline__ T unp_peek(const T *ptr)
+{
+    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave: true in every lane for the workgroup that arrives last of `expect` at *counter.
+// What the workgroup posted before has landed when it is counted.
+__device__ __forceinline__ bool unp_arrive_last(uint32_t *counter, uint32_t expect, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the posts have been acknowledged
+    uint32_t last = 0;
+    if (lane == 0) last = atomicAdd(counter, 1u) == expect - 1 ? 1u : 0u;
+    return __builtin_amdgcn_readfirstlane((int) last) != 0;
+}
+
+// A chunk's table is a function from entry state to (exit state, records) and the
+// chain through the chunks is their composition.  Lane x follows entry state x
+// through the chunks of run `run` (a row of the table per chunk in registers, lane
+// x holding entry x; a step is one shuffle) and leaves the run's table.
+constexpr int UNP_BATCH = 32;
+
+__device__ __forceinline__ void unp_compose_run(const UnpParams &p, uint32_t run, int lane)
+{
+    const uint32_t S = p.V + 2, x = min((uint32_t) lane, S - 1);
+    const uint32_t c0 = run * UNP_RUN, len = min(UNP_RUN, p.nchunks - c0);
+    uint32_t cur = x;
+    uint64_t cnt = 0;
+    for (uint32_t b = 0; b < len; b += UNP_BATCH) {
+        uint32_t row[UNP_BATCH];
+#pragma unroll
+        for (int j = 0; j < UNP_BATCH; j++) row[j] = unp_peek(&p.table[(uint64_t) min(c0 + b + j, p.nchunks - 1) * S + x]);
+#pragma unroll
+        for (int j = 0; j < UNP_BATCH; j++) {
+            if (b + j < len) {
+                const uint32_t t = (uint32_t) __shfl((int) row[j], (int) cur);
+                cnt += t & 0xFFFFFFu;
+                cur = t >> 24;
+            }
+        }
+    }
+    if ((uint32_t) lane < S) {
+        unp_post(&p.run_exit[(uint64_t) run * S + lane], cur);
+        unp_post(&p.run_count[(uint64_t) run * S + lane], cnt);
+    }
+}
+
+// State 0 (the stream starts at a record boundary) through the run tables: entry
+// state and first record of every run, the number of records, and whether the
+// stream ends where a record ends.
+__device__ __forceinline__ void unp_run_prefix(const UnpParams &p, int lane)
+{
+    const uint32_t S = p.V + 2, x = min((uint32_t) lane, S - 1);
+    uint32_t state = 0;
+    uint64_t total = 0;
+    for (uint32_t r0 = 0; r0 < p.nruns; r0 += UNP_BATCH) {
+        uint32_t ex[UNP_BATCH];
+        uint64_t cn[UNP_BATCH];
+#pragma unroll
+        for (int j = 0; j < UNP_BATCH; j++) {
+            const uint64_t at = (uint64_t) min(r0 + j, p.nruns - 1) * S + x;
+            ex[j] = unp_peek(&p.run_exit[at]);
+            cn[j] = unp_peek(&p.run_count[at]);
+        }
+        uint32_t my_entry = 0;
+        uint64_t my_first = 0;
+#pragma unroll
+        for (int j = 0; j < UNP_BATCH; j++) {
+            if (lane == j) {
+                my_entry = state;
+                my_first = total;
+            }
+            if (r0 + j < p.nruns) {
+                const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) cn[j], (int) state);
+                const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (cn[j] >> 32), (int) state);
+                total += ((uint64_t) hi << 32) | lo;
+                state = (uint32_t) __builtin_amdgcn_readlane((int) ex[j], (int) state);
+            }
+        }
+        if (lane < UNP_BATCH && r0 + lane < p.nruns) {
+            p.run_entry[r0 + lane] = my_entry;
+            p.run_first[r0 + lane] = my_first;
+        }
+    }
+    if (lane == 0) {
+        p.result[0] = total;
+        // the stream must end at a record boundary: nothing owed, not inside a key
+        if (state != 0) raise_error(p.ctrl, MGS_ERR_MALFORMED);
+        else if (total + 1 > p.rec_cap) raise_error(p.ctrl, MGS_ERR_ARG);
+    }
+}
+
 // States as table indices: 0..V = bytes to skip, V+1 = inside a key.
 // Dynamic LDS: states [S][65], counts [S][65] (a lane's column; the pitch of 65
 // keeps the composition's reads apart), then the 256 block masks.
@@ -231,95 +340,14 @@ __global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
             cnt += scn[cur * 65 + piece];
             cur = sst[cur * 65 + piece];
         }
-        p.table[(uint64_t) c * S + lane] = (cur << 24) | cnt; // a chunk is at most 2^21 bytes
+        unp_post(&p.table[(uint64_t) c * S + lane], (cur << 24) | cnt); // a chunk is at most 2^21 bytes
     }
-}
-
-// The chain through the chunks.  A chunk's table is a function from entry state
-// to (exit state, records) and the chain is their composition, so it is cut
-// into 16 runs, one wave each:
-//   1. lane x follows entry state x through the wave's run (a row of the table
-//      per chunk in registers, lane x holding entry x; a step is one shuffle);
-//   2. the run tables go through LDS, every wave follows state 0 through the
-//      runs before its own -> its entry state and first record;
-//   3. the wave follows that one state through its run again (a step is two
-//      register reads) and writes entry state and first record of every chunk.
-// Rows are fetched a batch ahead: their addresses do not depend on the chain.
-constexpr int UNP_CHAIN_WAVES = 16;
-
-__global__ __launch_bounds__(64 * UNP_CHAIN_WAVES) void k_unp_chain(UnpParams p)
-{
-    __shared__ uint32_t run_exit[UNP_CHAIN_WAVES][64];
-    __shared__ uint64_t run_count[UNP_CHAIN_WAVES][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t S = p.V + 2;
-    constexpr int BATCH = 32;
-    const uint32_t per = (p.nchunks + UNP_CHAIN_WAVES - 1) / UNP_CHAIN_WAVES;
-    const uint32_t cbeg = min(p.nchunks, (uint32_t) w * per), cend = min(p.nchunks, cbeg + per);
-    const uint32_t x = min((uint32_t) lane, S - 1);
-    auto fetch = [&](uint32_t c0, uint32_t (&row)[BATCH]) {
-#pragma unroll
-        for (int j = 0; j < BATCH; j++) row[j] = p.table[(uint64_t) min(c0 + j, p.nchunks - 1) * S + x];
-    };
-    uint32_t row[BATCH], ahead[BATCH];
-    {
-        uint32_t cur = x;
-        uint64_t cnt = 0;
-        if (cbeg < cend) fetch(cbeg, row);
-        for (uint32_t c0 = cbeg; c0 < cend; c0 += BATCH) {
-            if (c0 + BATCH < cend) fetch(c0 + BATCH, ahead);
-#pragma unroll
-            for (int j = 0; j < BATCH; j++) {
-                if (c0 + j < cend) {
-                    const uint32_t t = (uint32_t) __shfl((int) row[j], (int) cur);
-                    cnt += t & 0xFFFFFFu;
-                    cur = t >> 24;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < BATCH; j++) row[j] = ahead[j];
-        }
-        run_exit[w][lane] = cur;
-        run_count[w][lane] = cnt;
-    }
-    if (cbeg < cend) fetch(cbeg, row); // for the second pass, in flight across the barrier
-    __syncthreads();
-    uint32_t state = 0; // the stream starts at a record boundary
-    uint64_t total = 0;
-    for (int r = 0; r < w; r++) {
-        total += run_count[r][state];
-        state = run_exit[r][state];
-    }
-    for (uint32_t c0 = cbeg; c0 < cend; c0 += BATCH) {
-        if (c0 + BATCH < cend) fetch(c0 + BATCH, ahead);
-        uint32_t my_entry = 0;
-        uint64_t my_first = 0;
-#pragma unroll
-        for (int j = 0; j < BATCH; j++) {
-            if (lane == j) {
-                my_entry = state;
-                my_first = total;
-            }
-            if (c0 + j < cend) {
-                const uint32_t t = (uint32_t) __builtin_amdgcn_readlane((int) row[j], (int) state);
-                total += t & 0xFFFFFFu;
-                state = t >> 24;
-            }
-        }
-        if (lane < BATCH && c0 + lane < cend) {
-            p.entry[c0 + lane] = my_entry;
-            p.first_rec[c0 + lane] = my_first;
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; j++) row[j] = ahead[j];
-    }
-    if (w == UNP_CHAIN_WAVES - 1 && lane == 0) { // the last run ends the stream (an empty run passes its entry on)
-        p.first_rec[p.nchunks] = total;
-        p.result[0] = total;
-        // the stream must end at a record boundary: nothing owed, not inside a key
-        if (state != 0) raise_error(p.ctrl, MGS_ERR_MALFORMED);
-        else if (total + 1 > p.rec_cap) raise_error(p.ctrl, MGS_ERR_ARG);
-    }
+    // the last workgroup of a run composes the run, the last of those chains the runs
+    const uint32_t run = c / UNP_RUN;
+    if (!unp_arrive_last(&p.sync[2 + run], min(UNP_RUN, p.nchunks - run * UNP_RUN), lane)) return;
+    unp_compose_run(p, run, lane);
+    if (!unp_arrive_last(&p.sync[0], p.nruns, lane)) return;
+    unp_run_prefix(p, lane);
 }
 
 // A lane's record starts are consecutive entries of rec_off, a few per step, and
@@ -386,8 +414,26 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
         stab[i] = ((uint32_t) p.piece_exit[(uint64_t) c * UNP_PIECES * S + i] << 16)
                   | p.piece_count[(uint64_t) c * UNP_PIECES * S + i];
     __syncthreads();
+    // the run's entry state through the chunks before this one (lane x holds entry x of a chunk's row)
+    const uint32_t run = c / UNP_RUN, before = c - run * UNP_RUN;
+    uint32_t entry = (uint32_t) __builtin_amdgcn_readfirstlane((int) p.run_entry[run]);
+    uint64_t first = p.run_first[run];
+    for (uint32_t b = 0; b < before; b += UNP_BATCH) {
+        uint32_t row[UNP_BATCH];
+#pragma unroll
+        for (int j = 0; j < UNP_BATCH; j++)
+            row[j] = p.table[(uint64_t) min(run * UNP_RUN + b + j, p.nchunks - 1) * S + min((uint32_t) lane, S - 1)];
+#pragma unroll
+        for (int j = 0; j < UNP_BATCH; j++) {
+            if (b + j < before) {
+                const uint32_t t = (uint32_t) __builtin_amdgcn_readlane((int) row[j], (int) entry);
+                first += t & 0xFFFFFFu;
+                entry = t >> 24;
+            }
+        }
+    }
     // the chunk's entry state through the pieces, the same walk in every lane
-    uint32_t cur = p.entry[c], cnt = 0, mine = 0, base = 0;
+    uint32_t cur = entry, cnt = 0, mine = 0, base = 0;
     for (int piece = 0; piece < UNP_PIECES; piece++) {
         if (piece == lane) {
             mine = cur;
@@ -402,7 +448,7 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
     UnpSink sink;
     sink.slot = unp_lds + ((UNP_PIECES * S + 128 + 3) & ~3u) + UNP_SLOT_PITCH * lane;
     sink.out = p.rec_off - back;
-    sink.v = sink.v_first = p.first_rec[c] + base + back;
+    sink.v = sink.v_first = first + base + back;
     for (uint32_t b0 = 0; b0 < nb; b0 += AHEAD) {
 #pragma unroll
         for (uint32_t j = 0; j < AHEAD; j++) {
@@ -416,7 +462,7 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
         }
     }
     sink.finish();
-    if (c == p.nchunks - 1 && lane == 0) p.rec_off[p.first_rec[p.nchunks]] = (uint32_t) p.nbytes;
+    if (c == p.nchunks - 1 && lane == 0) p.rec_off[p.result[0]] = (uint32_t) p.nbytes;
 }
 
 // Fixed-width records: the offsets are multiples of the width.
@@ -436,26 +482,21 @@ __global__ void k_unp_fixed(UnpParams p, uint32_t width)
 // page if it fits exactly or with room to spare, else a new page is opened.
 // One wave: the last record that still fits is found by a search that probes 64
 // places at a time.
-__global__ __launch_bounds__(64) void k_unp_pages(UnpParams p)
+__device__ __forceinline__ void unp_pages_walk(const UnpParams &p, int lane)
 {
-    if (blockIdx.x != 0) return;
-    const int lane = threadIdx.x;
-    if (p.ctrl->head.error != 0) {
-        if (lane == 0) p.result[1] = 0;
-        return;
-    }
+    auto off = [&](uint64_t i) { return (uint64_t) p.rec_off[i]; };
     const uint64_t n = p.result[0];
     const uint64_t S = (uint64_t) p.page_bytes;
     uint64_t room = S - (uint64_t) p.first_fill; // bytes left in the current page
     uint64_t i = 0, ncuts = 0;
     while (i < n) {
         // largest j in [i, n] with rec_off[j] - rec_off[i] <= room
-        const uint64_t base = p.rec_off[i];
+        const uint64_t base = off(i);
         uint64_t lo = i, hi = n;
         while (lo < hi) {
             const uint64_t step = (hi - lo + 63) / 64;
             const uint64_t probe = min(hi, lo + (uint64_t) (lane + 1) * step);
-            const bool fits = (uint64_t) p.rec_off[probe] - base <= room;
+            const bool fits = off(probe) - base <= room;
             const uint64_t k = (uint64_t) __popcll(__ballot(fits)); // the offsets ascend: the first k probes fit
             const uint64_t nlo = min(hi, lo + k * step);
             hi = min(hi, lo + (k + 1) * step - 1);
@@ -468,13 +509,23 @@ __global__ __launch_bounds__(64) void k_unp_pages(UnpParams p)
         }
         if (ncuts < p.max_cuts && lane == 0) {
             p.cuts[2 * ncuts] = lo;
-            p.cuts[2 * ncuts + 1] = p.rec_off[lo];
+            p.cuts[2 * ncuts + 1] = off(lo);
         }
         ncuts++;
         i = lo;
         room = S;
     }
     if (lane == 0) p.result[1] = ncuts;
+}
+
+__global__ __launch_bounds__(64) void k_unp_pages(UnpParams p)
+{
+    if (blockIdx.x != 0) return;
+    if (p.ctrl->head.error != 0) {
+        if (threadIdx.x == 0) p.result[1] = 0;
+        return;
+    }
+    unp_pages_walk(p, threadIdx.x);
 }
 
 } // namespace mgs
