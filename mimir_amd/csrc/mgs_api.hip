@@ -1653,9 +1653,12 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
         hipLaunchKernelGGL(k_unp_fixed, dim3((unsigned) std::min<uint64_t>(4096, n / 256 + 1)), dim3(256), 0,
                            stream, p, h->fixed_len);
     }
+    else if (nbytes < 16) {
+        hipLaunchKernelGGL(k_unp_tiny, dim3(1), dim3(64), 0, stream, p);
+    }
     else {
         const size_t lds_spec = (2 * (size_t) S * 65 + 128) * sizeof(uint32_t);
-        const size_t lds_emit = ((((size_t) UNP_PIECES * S + 128 + 3) & ~(size_t) 3) + 64 * UNP_SLOT_PITCH) * sizeof(uint32_t);
+        const size_t lds_emit = ((size_t) unp_emit_table_dwords(S) + 64 * UNP_SLOT_PITCH) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_unp_spec, dim3(p.nchunks), dim3(64), lds_spec, stream, p);
         hipLaunchKernelGGL(k_unp_emit, dim3(p.nchunks), dim3(64), lds_emit, stream, p);
     }

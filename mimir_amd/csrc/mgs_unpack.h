@@ -83,22 +83,22 @@ struct __attribute__((packed)) UnpU128 { uint32_t x, y, z, w; };
 
 // The lane's 16 bytes p.stream[at .. at+16), fetched without ever reading past the
 // stream: a piece that sticks out is fetched 16 bytes back from the end instead
-// (unp_m16 shifts it into place).  Streams shorter than 16 bytes go byte by byte.
+// (unp_m16 shifts it into place).  One load and nothing else: with a second,
+// byte-wise path in here for streams under 16 bytes the compiler waited for every
+// load of the parse loop right where it was issued (the counters of both paths are
+// merged where they join).  Such streams take k_unp_tiny.
+// EDGE = false: the caller knows that at + 16 <= nbytes.
+template <bool EDGE = true>
 __device__ __forceinline__ uint4 unp_load16(const UnpParams &p, uint64_t at)
 {
-    if (p.nbytes < 16) {
-        uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        for (uint32_t i = 0; i < 16 && at + i < p.nbytes; i++)
-            w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t) p.stream[at + i] << (8 * (i & 3)));
-        return make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    const uint64_t a = min(at, p.nbytes - 16);
+    const uint64_t a = EDGE ? min(at, p.nbytes - 16) : at;
     const UnpU128 v = *reinterpret_cast<const UnpU128 *>(p.stream + a);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // Bit i of the result: byte i of the lane's 16 bytes at p.stream[at .. at+16) is a
 // NUL (bytes past the end of the stream count as non-NUL).  v = unp_load16(p, at).
+template <bool EDGE = true>
 __device__ __forceinline__ uint32_t unp_m16(const UnpParams &p, uint64_t at, const uint4 &v)
 {
     auto nibble = [](uint32_t w) { // one bit per zero byte, lowest address first
@@ -106,8 +106,9 @@ __device__ __forceinline__ uint32_t unp_m16(const UnpParams &p, uint64_t at, con
         return (((t >> 7) * 0x01020408u) >> 24) & 0xFu;
     };
     const uint32_t m = nibble(v.x) | (nibble(v.y) << 4) | (nibble(v.z) << 8) | (nibble(v.w) << 12);
+    if (!EDGE) return m;
     if (at >= p.nbytes) return 0;
-    if (p.nbytes >= 16 && at + 16 > p.nbytes) return m >> (uint32_t) (at - (p.nbytes - 16));
+    if (at + 16 > p.nbytes) return m >> (uint32_t) (at - (p.nbytes - 16));
     return m;
 }
 
@@ -122,19 +123,22 @@ __device__ __forceinline__ uint64_t unp_row_at(const UnpParams &p, uint64_t c0, 
     return c0 + (uint64_t) (16 * j + (lane >> 2)) * p.piece_bytes + 64u * b + 16u * (uint32_t) (lane & 3);
 }
 
+template <bool EDGE>
 __device__ __forceinline__ void unp_rows_load(const UnpParams &p, uint64_t c0, uint32_t b, int lane, UnpRows &r)
 {
 #pragma unroll
-    for (int j = 0; j < 4; j++) r.raw[j] = unp_load16(p, unp_row_at(p, c0, b, j, lane));
+    for (int j = 0; j < 4; j++) r.raw[j] = unp_load16<EDGE>(p, unp_row_at(p, c0, b, j, lane));
 }
 
 // The masks of the rows just loaded go to LDS (256 x 16 bit); the lane's own
 // 64-bit mask comes back.
+template <bool EDGE>
 __device__ __forceinline__ uint64_t unp_rows_mask(const UnpParams &p, uint64_t c0, uint32_t b, int lane,
                                                   const UnpRows &r, uint16_t *smask)
 {
 #pragma unroll
-    for (int j = 0; j < 4; j++) smask[64 * j + lane] = (uint16_t) unp_m16(p, unp_row_at(p, c0, b, j, lane), r.raw[j]);
+    for (int j = 0; j < 4; j++)
+        smask[64 * j + lane] = (uint16_t) unp_m16<EDGE>(p, unp_row_at(p, c0, b, j, lane), r.raw[j]);
     __syncthreads();
     const uint64_t nul = reinterpret_cast<const uint64_t *>(smask)[lane];
     __syncthreads();
@@ -270,36 +274,26 @@ __device__ __forceinline__ void unp_run_prefix(const UnpParams &p, int lane)
     }
 }
 
-// States as table indices: 0..V = bytes to skip, V+1 = inside a key.
-// Dynamic LDS: states [S][65], counts [S][65] (a lane's column; the pitch of 65
-// keeps the composition's reads apart), then the 256 block masks.
-__global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
+// The blocks of k_unp_spec's chunk c.  EDGE = false: the chunk and 16 bytes behind it are inside the stream.
+template <bool EDGE>
+__device__ __forceinline__ void unp_spec_blocks(const UnpParams &p, uint32_t c, int lane, uint32_t *sst, uint32_t *scn,
+                                                uint16_t *smask, bool &merged, uint32_t &state, uint32_t &dn)
 {
-    extern __shared__ uint32_t unp_lds[];
-    const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x, V = p.V, S = V + 2;
-    uint32_t *sst = unp_lds, *scn = unp_lds + S * 65;
-    uint16_t *smask = reinterpret_cast<uint16_t *>(unp_lds + 2 * S * 65);
+    const uint32_t V = p.V, S = V + 2;
     const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
     const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
     const uint64_t a1 = min(p.nbytes, a0 + p.piece_bytes); // a1 <= a0: the piece is empty
-    for (uint32_t x = 0; x < S; x++) {
-        sst[x * 65 + lane] = (x == V + 1) ? UNP_INKEY : x;
-        scn[x * 65 + lane] = 0;
-    }
-    bool merged = false; // every entry state of this lane has led to the same state
-    uint32_t state = 0, dn = 0;
     const uint32_t nb = p.piece_bytes / 64;
     UnpRows rows;
-    unp_rows_load(p, c0, 0, lane, rows);
+    unp_rows_load<EDGE>(p, c0, 0, lane, rows);
     for (uint32_t b = 0; b < nb; b++) {
         const UnpRows cur = rows;
-        if (b + 1 < nb) unp_rows_load(p, c0, b + 1, lane, rows); // in flight during the parse
-        const uint64_t nul = unp_rows_mask(p, c0, b, lane, cur, smask);
+        if (b + 1 < nb) unp_rows_load<EDGE>(p, c0, b + 1, lane, rows); // in flight during the parse
+        const uint64_t nul = unp_rows_mask<EDGE>(p, c0, b, lane, cur, smask);
         p.masks[((uint64_t) c * nb + b) * 64 + lane] = nul; // one 512-byte row per step: k_unp_emit parses from these
         const uint64_t boff = a0 + 64u * b;
-        if (boff >= a1) continue;
-        const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
+        if (EDGE && boff >= a1) continue;
+        const uint32_t valid = EDGE ? (uint32_t) min((uint64_t) 64, a1 - boff) : 64u;
         if (merged) {
             state = unp_step(nul, state, V, valid, [&](uint32_t) { dn++; });
             continue;
@@ -323,6 +317,28 @@ __global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
             state = first;
         }
     }
+}
+
+// States as table indices: 0..V = bytes to skip, V+1 = inside a key.
+// Dynamic LDS: states [S][65], counts [S][65] (a lane's column; the pitch of 65
+// keeps the composition's reads apart), then the 256 block masks.
+__global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
+{
+    extern __shared__ uint32_t unp_lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x, V = p.V, S = V + 2;
+    uint32_t *sst = unp_lds, *scn = unp_lds + S * 65;
+    uint16_t *smask = reinterpret_cast<uint16_t *>(unp_lds + 2 * S * 65);
+    const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
+    for (uint32_t x = 0; x < S; x++) {
+        sst[x * 65 + lane] = (x == V + 1) ? UNP_INKEY : x;
+        scn[x * 65 + lane] = 0;
+    }
+    bool merged = false; // every entry state of this lane has led to the same state
+    uint32_t state = 0, dn = 0;
+    // a chunk with 16 bytes of stream behind it needs no care at its end
+    if (c0 + p.chunk_bytes + 16 <= p.nbytes) unp_spec_blocks<false>(p, c, lane, sst, scn, smask, merged, state, dn);
+    else unp_spec_blocks<true>(p, c, lane, sst, scn, smask, merged, state, dn);
     for (uint32_t x = 0; x < S; x++) {
         const uint32_t e = merged ? state : sst[x * 65 + lane];
         sst[x * 65 + lane] = (e & UNP_INKEY) ? V + 1 : e; // at most V bytes are ever owed after a NUL
@@ -350,49 +366,110 @@ __global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
     unp_run_prefix(p, lane);
 }
 
-// A lane's record starts are consecutive entries of rec_off, a few per step, and
-// the 64 lanes write to 64 places: stored one by one every store instruction
-// touches 64 lines for 4 bytes each.  So a lane collects its entries in LDS, in
-// groups of 16 that are 64-byte groups of rec_off (counted from a 16-byte
-// boundary at or below rec_off), and writes a group with four 16-byte stores
-// when it is complete; the entries of a group that the lane shares with its
-// neighbour (the first and the last of its piece) go one by one.
-constexpr int UNP_SLOT_PITCH = 20; // dwords per lane: 16 entries, padded so that 16-byte reads of 8 lanes fill the banks
+// A lane's record starts are consecutive entries of rec_off, a few per block, and
+// the 64 lanes write to 64 places.  Stored one by one every store instruction
+// touches 64 lines for 4 bytes each (0.79 ms per 6e7 records); stored by the lane
+// as the four 16-byte pieces of a 64-byte group it still is 64 lines per
+// instruction (0.11 ms of the kernel's 0.21).  So a lane collects its entries in a
+// ring in LDS, and after every block the wave stores the groups that are complete
+// together: four lanes per group, one 16-byte piece each, sixteen groups per store
+// instruction, every group one 64-byte request.  Groups are 64-byte groups of
+// rec_off counted from a 64-byte boundary at or below it; the entries of the
+// group a lane shares with its neighbour (the first and the last of its piece) go
+// one by one.
+constexpr uint32_t UNP_RING = 24;  // entries a lane keeps: a group of 16 and what a block adds before the wave stores
+constexpr int UNP_SLOT_PITCH = 28; // dwords per lane: 16-byte reads of 8 lanes at this pitch fall into different banks
+constexpr int UNP_LIST_DWORDS = 3 * 64;
+
+// Dwords of the piece tables in k_unp_emit's LDS (room for the list that takes their place).
+__host__ __device__ inline uint32_t unp_emit_table_dwords(uint32_t S)
+{
+    const uint32_t t = (uint32_t) UNP_PIECES * S;
+    return ((t > (uint32_t) UNP_LIST_DWORDS ? t : (uint32_t) UNP_LIST_DWORDS) + 3u) & ~3u;
+}
 
 struct UnpSink {
-    uint32_t *slot;    // this lane's 16 entries in LDS
-    uint32_t *out;     // rec_off moved back to a 16-byte boundary
+    uint32_t *rings;   // lane 0's ring in LDS; a lane's own is at UNP_SLOT_PITCH * lane
+    uint32_t *ring;    // this lane's
+    uint32_t *list;    // [64][3]: lane << 8 | ring position of a group to store, its first entry (two words)
+    uint32_t *out;     // rec_off moved back to a 64-byte boundary
     uint64_t v;        // next entry to write, counted from `out`
     uint64_t v_first;  // first entry of this lane
+    uint64_t v_done;   // a multiple of 16: the entries below it are stored (or another lane's)
+    uint32_t rp, rp_done; // ring positions of v and v_done
 
+    __device__ __forceinline__ void start(uint64_t first)
+    {
+        v = v_first = first;
+        v_done = first & ~(uint64_t) 15;
+        rp_done = 0;
+        rp = (uint32_t) (v - v_done);
+    }
     __device__ __forceinline__ void put(uint32_t value)
     {
-        slot[(uint32_t) v & 15u] = value;
+        if (v - v_done >= UNP_RING) store_own(); // more than 8 records in a block: values of fewer than 7 bytes only
+        ring[rp] = value;
+        rp = (rp + 1 == UNP_RING) ? 0 : rp + 1;
         v++;
-        if (((uint32_t) v & 15u) == 0) flush_group();
     }
-    __device__ __forceinline__ void flush_group() // the group that ends at v
+    __device__ __forceinline__ void advance_done()
     {
-        const uint64_t g = v - 16;
-        if (g >= v_first) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(slot);
-            uint4 *dst = reinterpret_cast<uint4 *>(out + g);
-#pragma unroll
-            for (int i = 0; i < 4; i++) dst[i] = src[i];
+        v_done += 16;
+        rp_done = (rp_done + 16 >= UNP_RING) ? rp_done + 16 - UNP_RING : rp_done + 16;
+    }
+    __device__ __forceinline__ void store_own() // the oldest group, entry by entry
+    {
+        for (uint32_t e = 0; e < 16; e++) {
+            const uint32_t at = rp_done + e;
+            if (v_done + e >= v_first) out[v_done + e] = ring[at >= UNP_RING ? at - UNP_RING : at];
         }
-        else {
-            for (uint32_t e = (uint32_t) v_first & 15u; e < 16; e++) out[g + e] = slot[e];
+        advance_done();
+    }
+    // The whole wave: every complete group of every lane.
+    __device__ __forceinline__ void store_ready(int lane)
+    {
+        for (;;) {
+            bool pend = v - v_done >= 16;
+            if (pend && v_done < v_first) { // shared with the neighbour
+                store_own();
+                pend = v - v_done >= 16;
+            }
+            const uint64_t m = __ballot(pend);
+            if (m == 0) break;
+            if (pend) {
+                const uint32_t r = lanes_below(m);
+                list[3 * r] = ((uint32_t) lane << 8) | rp_done;
+                list[3 * r + 1] = (uint32_t) v_done;
+                list[3 * r + 2] = (uint32_t) (v_done >> 32);
+            }
+            asm volatile("" ::: "memory"); // one wave: its LDS accesses complete in order
+            const uint32_t n = (uint32_t) __popcll(m);
+            for (uint32_t e0 = 0; e0 < n; e0 += 16) {
+                const uint32_t e = e0 + ((uint32_t) lane >> 2);
+                if (e < n) {
+                    const uint32_t w = list[3 * e];
+                    const uint64_t first = (uint64_t) list[3 * e + 1] | ((uint64_t) list[3 * e + 2] << 32);
+                    uint32_t at = (w & 0xFFu) + 4u * ((uint32_t) lane & 3u);
+                    if (at >= UNP_RING) at -= UNP_RING;
+                    const uint4 piece = *reinterpret_cast<const uint4 *>(rings + UNP_SLOT_PITCH * (w >> 8) + at);
+                    *reinterpret_cast<uint4 *>(out + first + 4u * ((uint32_t) lane & 3u)) = piece;
+                }
+            }
+            asm volatile("" ::: "memory");
+            if (pend) advance_done();
         }
     }
-    __device__ __forceinline__ void finish() // the incomplete last group
+    __device__ __forceinline__ void finish() // what is left: less than a group, or the groups of a wave that stopped early
     {
-        const uint64_t g = v & ~(uint64_t) 15;
-        for (uint64_t i = max(g, v_first); i < v; i++) out[i] = slot[(uint32_t) i & 15u];
+        for (uint64_t i = max(v_done, v_first); i < v; i++) {
+            const uint32_t at = rp_done + (uint32_t) (i - v_done);
+            out[i] = ring[at >= UNP_RING ? at - UNP_RING : at];
+        }
     }
 };
 
-// Dynamic LDS: the chunk's piece tables as (exit << 16 | count) [64][S], the 256
-// block masks, the lanes' entry groups.
+// Dynamic LDS: the chunk's piece tables as (exit << 16 | count) [64][S] -- the list of groups to
+// store once they have been walked -- and the lanes' rings.
 __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
 {
     extern __shared__ uint32_t unp_lds[];
@@ -444,11 +521,13 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
         cur = t >> 16;
     }
     uint32_t state = (mine == V + 1) ? UNP_INKEY : mine;
-    const uint32_t back = (uint32_t) ((reinterpret_cast<uintptr_t>(p.rec_off) >> 2) & 3u);
+    const uint32_t back = (uint32_t) ((reinterpret_cast<uintptr_t>(p.rec_off) >> 2) & 15u);
     UnpSink sink;
-    sink.slot = unp_lds + ((UNP_PIECES * S + 128 + 3) & ~3u) + UNP_SLOT_PITCH * lane;
+    sink.list = unp_lds;
+    sink.rings = unp_lds + unp_emit_table_dwords(S);
+    sink.ring = sink.rings + UNP_SLOT_PITCH * lane;
     sink.out = p.rec_off - back;
-    sink.v = sink.v_first = first + base + back;
+    sink.start(first + base + back);
     for (uint32_t b0 = 0; b0 < nb; b0 += AHEAD) {
 #pragma unroll
         for (uint32_t j = 0; j < AHEAD; j++) {
@@ -456,13 +535,43 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
             const uint64_t nul = mq[j];
             if (b + AHEAD < nb) mq[j] = mrow[(uint64_t) (b + AHEAD) * 64]; // in flight during the parse
             const uint64_t boff = a0 + 64u * b;
-            if (b >= nb || boff >= a1) continue;
-            const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
-            state = unp_step(nul, state, V, valid, [&](uint32_t pos) { sink.put((uint32_t) boff + pos); });
+            if (b >= nb) continue;
+            if (boff < a1) {
+                const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
+                state = unp_step(nul, state, V, valid, [&](uint32_t pos) { sink.put((uint32_t) boff + pos); });
+            }
+            sink.store_ready(lane);
         }
     }
     sink.finish();
     if (c == p.nchunks - 1 && lane == 0) p.rec_off[p.result[0]] = (uint32_t) p.nbytes;
+}
+
+// A stream of fewer than 16 bytes: one lane walks it, first to count, then to write.
+__global__ void k_unp_tiny(UnpParams p)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t n = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        uint64_t pos = 0;
+        n = 0;
+        while (pos < p.nbytes) {
+            if (pass) p.rec_off[n] = (uint32_t) pos;
+            n++;
+            while (pos < p.nbytes && p.stream[pos] != 0) pos++;
+            pos = (pos < p.nbytes) ? pos + 1 + p.V : p.nbytes + 1; // a key that does not end
+        }
+        if (pos != p.nbytes) { // the stream must end at a record boundary
+            raise_error(p.ctrl, MGS_ERR_MALFORMED);
+            return;
+        }
+        if (n + 1 > p.rec_cap) {
+            raise_error(p.ctrl, MGS_ERR_ARG);
+            return;
+        }
+    }
+    p.rec_off[n] = (uint32_t) p.nbytes;
+    p.result[0] = n;
 }
 
 // Fixed-width records: the offsets are multiples of the width.

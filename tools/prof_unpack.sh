@@ -1,10 +1,11 @@
 #!/bin/bash
-# Kernel times of mgs_unpack_device on 6e7 word records.  Usage (on the GPU box): bash tools/prof_unpack.sh [tag]
+# Kernel times of mgs_unpack_device on 6e7 word records.  Usage (on the GPU box): bash tools/prof_unpack.sh [tag] [library]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-unp}
+export MGS_LIBRARY=$2
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/$TAG
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -- python3 $R/tools/bench_unpack.py 6e7 5 > $R/gpurun_out/$TAG.log 2>&1 || exit 1
-cat $R/gpurun_out/$TAG.log | cut -c1-200
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -- python3 $R/tools/bench_unpack.py 6e7 5 > $R/gpurun_out/$TAG.log 2>&1
+grep workload $R/gpurun_out/$TAG.log | cut -c1-200
 f=$(ls -t $(find $R/gpurun_out/$TAG -name '*kernel_stats.csv') | head -1)
-cut -c1-150 $f | head -8
+cut -c1-150 $f | head -4
