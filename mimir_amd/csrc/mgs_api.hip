@@ -1600,7 +1600,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     const uint32_t S = p.V + 2;
     // one wave per chunk, one lane per piece; pieces of at least four 64-byte blocks
     uint64_t chunk = (nbytes + parse_chunks() - 1) / parse_chunks();
-    chunk = std::max<uint64_t>(16384, (chunk + 4095) / 4096 * 4096);
+    chunk = std::max<uint64_t>(16384, (chunk + 8191) / 8192 * 8192); // 64 pieces, each a multiple of 128 bytes
     p.chunk_bytes = (uint32_t) chunk;
     p.piece_bytes = (uint32_t) (chunk / UNP_PIECES);
     p.nchunks = (uint32_t) ((nbytes + chunk - 1) / chunk);
@@ -1657,7 +1657,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
         hipLaunchKernelGGL(k_unp_tiny, dim3(1), dim3(64), 0, stream, p);
     }
     else {
-        const size_t lds_spec = (2 * (size_t) S * 65 + 128) * sizeof(uint32_t);
+        const size_t lds_spec = (((2 * (size_t) S * 65 + 3) & ~(size_t) 3) + 256) * sizeof(uint32_t);
         const size_t lds_emit = ((size_t) unp_emit_table_dwords(S) + 64 * UNP_SLOT_PITCH) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_unp_spec, dim3(p.nchunks), dim3(64), lds_spec, stream, p);
         hipLaunchKernelGGL(k_unp_emit, dim3(p.nchunks), dim3(64), lds_emit, stream, p);

@@ -112,37 +112,40 @@ __device__ __forceinline__ uint32_t unp_m16(const UnpParams &p, uint64_t at, con
     return m;
 }
 
-// Block b of all 64 pieces of the chunk at c0: load j (0..3) of a lane covers 16
-// bytes of row 16j + lane/4, so one load instruction reads 16 rows x 64 bytes.
+// Blocks 2s and 2s+1 of all 64 pieces of the chunk at c0: load j (0..7) of a lane covers 16
+// bytes of row 8j + lane/8, so one load instruction reads 8 rows x 128 contiguous bytes.
+// (With 64 bytes of a row per instruction -- one block at a time -- the kernel ran at 3.6 TB/s
+// whatever was done to the parse or to the number of loads in flight.)
 struct UnpRows {
-    uint4 raw[4];
+    uint4 raw[8];
 };
 
-__device__ __forceinline__ uint64_t unp_row_at(const UnpParams &p, uint64_t c0, uint32_t b, int j, int lane)
+__device__ __forceinline__ uint64_t unp_row_at(const UnpParams &p, uint64_t c0, uint32_t s, int j, int lane)
 {
-    return c0 + (uint64_t) (16 * j + (lane >> 2)) * p.piece_bytes + 64u * b + 16u * (uint32_t) (lane & 3);
+    return c0 + (uint64_t) (8 * j + (lane >> 3)) * p.piece_bytes + 128u * s + 16u * (uint32_t) (lane & 7);
 }
 
 template <bool EDGE>
-__device__ __forceinline__ void unp_rows_load(const UnpParams &p, uint64_t c0, uint32_t b, int lane, UnpRows &r)
+__device__ __forceinline__ void unp_rows_load(const UnpParams &p, uint64_t c0, uint32_t s, int lane, UnpRows &r)
 {
 #pragma unroll
-    for (int j = 0; j < 4; j++) r.raw[j] = unp_load16<EDGE>(p, unp_row_at(p, c0, b, j, lane));
+    for (int j = 0; j < 8; j++) r.raw[j] = unp_load16<EDGE>(p, unp_row_at(p, c0, s, j, lane));
 }
 
-// The masks of the rows just loaded go to LDS (256 x 16 bit); the lane's own
-// 64-bit mask comes back.
+// The masks of the rows just loaded go to LDS (512 x 16 bit); the lane's own two
+// 64-bit masks come back.
 template <bool EDGE>
-__device__ __forceinline__ uint64_t unp_rows_mask(const UnpParams &p, uint64_t c0, uint32_t b, int lane,
-                                                  const UnpRows &r, uint16_t *smask)
+__device__ __forceinline__ void unp_rows_mask(const UnpParams &p, uint64_t c0, uint32_t s, int lane, const UnpRows &r,
+                                              uint16_t *smask, uint64_t &nul0, uint64_t &nul1)
 {
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-        smask[64 * j + lane] = (uint16_t) unp_m16<EDGE>(p, unp_row_at(p, c0, b, j, lane), r.raw[j]);
+    for (int j = 0; j < 8; j++)
+        smask[64 * j + lane] = (uint16_t) unp_m16<EDGE>(p, unp_row_at(p, c0, s, j, lane), r.raw[j]);
     __syncthreads();
-    const uint64_t nul = reinterpret_cast<const uint64_t *>(smask)[lane];
+    const uint4 m = reinterpret_cast<const uint4 *>(smask)[lane];
     __syncthreads();
-    return nul;
+    nul0 = (uint64_t) m.x | ((uint64_t) m.y << 32);
+    nul1 = (uint64_t) m.z | ((uint64_t) m.w << 32);
 }
 
 // One 64-byte block for one state.  state: bytes to skip before the next key
@@ -203,6 +206,9 @@ __device__ __forceinline__ bool unp_arrive_last(uint32_t *counter, uint32_t expe
 // through the chunks of run `run` (a row of the table per chunk in registers, lane
 // x holding entry x; a step is one shuffle) and leaves the run's table.
 constexpr int UNP_BATCH = 32;
+#ifndef UNP_AHEAD
+#define UNP_AHEAD 2
+#endif
 
 __device__ __forceinline__ void unp_compose_run(const UnpParams &p, uint32_t run, int lane)
 {
@@ -284,19 +290,20 @@ __device__ __forceinline__ void unp_spec_blocks(const UnpParams &p, uint32_t c, 
     const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
     const uint64_t a1 = min(p.nbytes, a0 + p.piece_bytes); // a1 <= a0: the piece is empty
     const uint32_t nb = p.piece_bytes / 64;
-    UnpRows rows;
-    unp_rows_load<EDGE>(p, c0, 0, lane, rows);
-    for (uint32_t b = 0; b < nb; b++) {
-        const UnpRows cur = rows;
-        if (b + 1 < nb) unp_rows_load<EDGE>(p, c0, b + 1, lane, rows); // in flight during the parse
-        const uint64_t nul = unp_rows_mask<EDGE>(p, c0, b, lane, cur, smask);
-        p.masks[((uint64_t) c * nb + b) * 64 + lane] = nul; // one 512-byte row per step: k_unp_emit parses from these
+    // UNP_AHEAD steps of two blocks in flight, each in registers of its own (no moves: a move would wait for its load)
+    const uint32_t ns = nb / 2; // pieces are multiples of 128 bytes
+    UnpRows ring[UNP_AHEAD];
+#pragma unroll
+    for (uint32_t j = 0; j < UNP_AHEAD; j++)
+        if (j < ns) unp_rows_load<EDGE>(p, c0, j, lane, ring[j]);
+    auto block = [&](uint32_t b, uint64_t nul) {
+        p.masks[((uint64_t) c * nb + b) * 64 + lane] = nul; // one 512-byte row per block: k_unp_emit parses from these
         const uint64_t boff = a0 + 64u * b;
-        if (EDGE && boff >= a1) continue;
+        if (EDGE && boff >= a1) return;
         const uint32_t valid = EDGE ? (uint32_t) min((uint64_t) 64, a1 - boff) : 64u;
         if (merged) {
             state = unp_step(nul, state, V, valid, [&](uint32_t) { dn++; });
-            continue;
+            return;
         }
         uint32_t prev_in = 0xFFFFFFFFu, out = 0, dnx = 0, first = 0;
         bool same = true;
@@ -316,19 +323,32 @@ __device__ __forceinline__ void unp_spec_blocks(const UnpParams &p, uint32_t c, 
             merged = true;
             state = first;
         }
+    };
+    for (uint32_t s0 = 0; s0 < ns; s0 += UNP_AHEAD) {
+#pragma unroll
+        for (uint32_t j = 0; j < UNP_AHEAD; j++) {
+            const uint32_t st = s0 + j;
+            if (st < ns) {
+                uint64_t nul0, nul1;
+                unp_rows_mask<EDGE>(p, c0, st, lane, ring[j], smask, nul0, nul1);
+                if (st + UNP_AHEAD < ns) unp_rows_load<EDGE>(p, c0, st + UNP_AHEAD, lane, ring[j]); // in flight during the next parses
+                block(2 * st, nul0);
+                block(2 * st + 1, nul1);
+            }
+        }
     }
 }
 
 // States as table indices: 0..V = bytes to skip, V+1 = inside a key.
 // Dynamic LDS: states [S][65], counts [S][65] (a lane's column; the pitch of 65
-// keeps the composition's reads apart), then the 256 block masks.
+// keeps the composition's reads apart), then the 512 sixteen-byte masks of a step.
 __global__ __launch_bounds__(64) void k_unp_spec(UnpParams p)
 {
     extern __shared__ uint32_t unp_lds[];
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x, V = p.V, S = V + 2;
     uint32_t *sst = unp_lds, *scn = unp_lds + S * 65;
-    uint16_t *smask = reinterpret_cast<uint16_t *>(unp_lds + 2 * S * 65);
+    uint16_t *smask = reinterpret_cast<uint16_t *>(unp_lds + ((2 * S * 65 + 3) & ~3u)); // read 16 bytes at a time
     const uint64_t c0 = (uint64_t) c * p.chunk_bytes;
     for (uint32_t x = 0; x < S; x++) {
         sst[x * 65 + lane] = (x == V + 1) ? UNP_INKEY : x;
@@ -598,15 +618,26 @@ __device__ __forceinline__ void unp_pages_walk(const UnpParams &p, int lane)
     const uint64_t S = (uint64_t) p.page_bytes;
     uint64_t room = S - (uint64_t) p.first_fill; // bytes left in the current page
     uint64_t i = 0, ncuts = 0;
+    uint64_t base = n ? off(0) : 0; // rec_off[i]
     while (i < n) {
         // largest j in [i, n] with rec_off[j] - rec_off[i] <= room
-        const uint64_t base = off(i);
         uint64_t lo = i, hi = n;
+        {
+            // first the neighbourhood of where the cut falls for records of the mean length
+            const uint64_t est = min(n, i + min(room, p.nbytes) * n / p.nbytes);
+            const uint64_t w = 2048;
+            const uint64_t q0 = est > i + w ? est - w : i;
+            const uint64_t probe = min(hi, q0 + (uint64_t) lane * (2 * w / 64));
+            const bool fits = off(probe) - base <= room;
+            const uint64_t k = (uint64_t) __popcll(__ballot(fits)); // the offsets ascend: the first k probes fit
+            if (k > 0) lo = min(hi, q0 + (k - 1) * (2 * w / 64));
+            if (k < 64) hi = min(hi, q0 + k * (2 * w / 64)) - 1; // probe k does not fit
+        }
         while (lo < hi) {
             const uint64_t step = (hi - lo + 63) / 64;
             const uint64_t probe = min(hi, lo + (uint64_t) (lane + 1) * step);
             const bool fits = off(probe) - base <= room;
-            const uint64_t k = (uint64_t) __popcll(__ballot(fits)); // the offsets ascend: the first k probes fit
+            const uint64_t k = (uint64_t) __popcll(__ballot(fits));
             const uint64_t nlo = min(hi, lo + k * step);
             hi = min(hi, lo + (k + 1) * step - 1);
             lo = nlo;
@@ -616,9 +647,10 @@ __device__ __forceinline__ void unp_pages_walk(const UnpParams &p, int lane)
             if (lane == 0) raise_error(p.ctrl, MGS_ERR_RECORD_SIZE);
             break;
         }
+        base = off(lo);
         if (ncuts < p.max_cuts && lane == 0) {
             p.cuts[2 * ncuts] = lo;
-            p.cuts[2 * ncuts + 1] = off(lo);
+            p.cuts[2 * ncuts + 1] = base;
         }
         ncuts++;
         i = lo;
