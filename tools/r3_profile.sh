@@ -31,3 +31,9 @@ for w in words join "octree --level 12"; do
   bash $R/tools/pmc_traffic.sh r3_$t bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $w > $O/traffic_$t.txt 2>&1
   head -3 $O/traffic_$t.txt
 done
+# the receive-side parse: blocking call time, then its kernels
+timeout -k 10 200 python3 $R/tools/bench_unpack.py 6e7 9 > $O/unpack.jsonl 2> /dev/null
+cat $O/unpack.jsonl | cut -c1-220
+bash $R/tools/prof_unpack.sh r3/unpack_stats > /dev/null 2>&1
+cp $(ls -t $(find $O/unpack_stats -name '*kernel_stats.csv') | head -1) $O/unpack_kernel_stats.csv
+head -5 $O/unpack_kernel_stats.csv
