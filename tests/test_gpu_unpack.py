@@ -27,7 +27,10 @@ def check(oracle, blob, lay_t, page_bytes, first_fill=0):
     want_off = oracle.parse_records(olay, blob)
     want_cuts = oracle.page_cuts(want_off, page_bytes, first_fill)
     d = torch.from_numpy(np.ascontiguousarray(blob)).cuda() if len(blob) else torch.empty(1, dtype=torch.uint8, device="cuda")
-    rec_off, n, cuts = unpack_stream(pk, d, len(blob), page_bytes, first_fill, max_cuts=4096)
+    room = None  # the wrapper's own buffer has room for records of two bytes and more
+    if len(want_off) + 1 > len(blob) // 2 + 2:
+        room = torch.empty(len(want_off) + 1, dtype=torch.int32, device="cuda")
+    rec_off, n, cuts = unpack_stream(pk, d, len(blob), page_bytes, first_fill, max_cuts=4096, rec_off=room)
     assert n == len(want_off) - 1
     got = rec_off[:n + 1].cpu().numpy().view(np.uint32).astype(np.uint64)
     assert np.array_equal(got, want_off)
@@ -75,6 +78,28 @@ def test_unpack_value_widths(oracle, vbytes):
     blob = np.frombuffer(b"".join(parts), dtype=np.uint8)
     lay = (capi.KEY_CSTR, 0, capi.VAL_FIXED, vbytes) if vbytes else (capi.KEY_CSTR, 0, capi.VAL_VOID, 0)
     check(oracle, blob, lay, 10000, first_fill=9990)
+
+
+@pytest.mark.parametrize("vbytes,klen", [(0, 0), (0, 1), (1, 0), (2, 1), (6, 0)])
+def test_unpack_dense_records(oracle, vbytes, klen):
+    """Records of one to seven bytes: more record starts in a 64-byte block than a lane's ring of
+    offsets takes between two of the wave's stores."""
+    n = 300000
+    rec = b"k" * klen + b"\0" + b"\0" * vbytes
+    blob = np.frombuffer(rec * n, dtype=np.uint8)
+    lay = (capi.KEY_CSTR, 0, capi.VAL_FIXED, vbytes) if vbytes else (capi.KEY_CSTR, 0, capi.VAL_VOID, 0)
+    got_n, _ = check(oracle, blob, lay, 1 << 16, first_fill=77)
+    assert got_n == n
+
+
+@pytest.mark.parametrize("nbytes", [1, 2, 9, 15, 16, 17, 31, 33])
+def test_unpack_streams_around_sixteen_bytes(oracle, nbytes):
+    """Streams under 16 bytes take a kernel of their own."""
+    blob = np.frombuffer(b"\0" * nbytes, dtype=np.uint8)  # empty keys, no value
+    check(oracle, blob, (capi.KEY_CSTR, 0, capi.VAL_VOID, 0), 5)
+    if nbytes % 3 == 0:
+        blob = np.frombuffer(b"a\0\7" * (nbytes // 3), dtype=np.uint8)
+        check(oracle, blob, (capi.KEY_CSTR, 0, capi.VAL_FIXED, 1), 7, first_fill=3)
 
 
 def test_unpack_join_and_fixed(oracle):
