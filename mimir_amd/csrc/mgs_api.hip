@@ -1590,7 +1590,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
         return MGS_ERR_HIP;
     }
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
-    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
+    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (4 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
 
     UnpParams p;
     memset(&p, 0, sizeof(p));
@@ -1608,7 +1608,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     const size_t tables = (size_t) p.nchunks * UNP_PIECES * S;
     p.nruns = (p.nchunks + UNP_RUN - 1) / UNP_RUN;
     const size_t sync_bytes = up((2 + (size_t) p.nruns) * sizeof(uint32_t));
-    const size_t need = up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t)) + sync_bytes
+    const size_t need = up((4 + 2 * kUnpMaxCuts) * sizeof(uint64_t)) + sync_bytes
                         + up((size_t) p.nchunks * S * sizeof(uint32_t))
                         + up((size_t) p.nruns * S * sizeof(uint32_t)) + up((size_t) p.nruns * S * sizeof(uint64_t))
                         + up((size_t) p.nruns * sizeof(uint32_t)) + up((size_t) p.nruns * sizeof(uint64_t))
@@ -1621,7 +1621,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     { const int rc = ensure_unp_scratch(h, need); if (rc) return rc; }
     uint8_t *q = h->d_unp;
     p.result = reinterpret_cast<uint64_t *>(q); // result and cuts leave with one copy
-    p.cuts = p.result + 2;                                    q += up((2 + 2 * kUnpMaxCuts) * sizeof(uint64_t));
+    p.cuts = p.result + 4;                                    q += up((4 + 2 * kUnpMaxCuts) * sizeof(uint64_t));
     p.sync = reinterpret_cast<uint32_t *>(q);                 q += sync_bytes;
     p.table = reinterpret_cast<uint32_t *>(q);                q += up((size_t) p.nchunks * S * sizeof(uint32_t));
     p.run_exit = reinterpret_cast<uint32_t *>(q);             q += up((size_t) p.nruns * S * sizeof(uint32_t));
@@ -1639,7 +1639,7 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     p.max_cuts = kUnpMaxCuts;
 
     MGS_HIP(h, hipMemsetAsync(&h->d_ctrl->head.error, 0, sizeof(int32_t), stream));
-    MGS_HIP(h, hipMemsetAsync(p.result, 0, 2 * sizeof(uint64_t), stream));
+    MGS_HIP(h, hipMemsetAsync(p.result, 0, 4 * sizeof(uint64_t), stream));
     if (nbytes && !fixed) MGS_HIP(h, hipMemsetAsync(p.sync, 0, sync_bytes, stream));
     if (nbytes == 0) {
         MGS_HIP(h, hipMemsetAsync(d_rec_off, 0, sizeof(uint32_t), stream));
@@ -1664,12 +1664,11 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     }
     hipLaunchKernelGGL(k_unp_pages, dim3(1), dim3(64), 0, stream, p);
     MGS_HIP(h, hipGetLastError());
-    MGS_HIP(h, hipMemcpyAsync(h->h_unp, p.result, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, stream));
-    MGS_HIP(h, hipMemcpyAsync(&h->h_ctrl->head.error, &h->d_ctrl->head.error, sizeof(int32_t),
-                              hipMemcpyDeviceToHost, stream));
+    // records, cuts, status and the first cuts in one small copy; the other cuts only when there are any
+    constexpr uint64_t kHeadCuts = 62;
+    MGS_HIP(h, hipMemcpyAsync(h->h_unp, p.result, (4 + 2 * kHeadCuts) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     MGS_HIP(h, hipStreamSynchronize(stream));
-    const int derr = h->h_ctrl->head.error;
+    const int derr = (int) (int32_t) (uint32_t) h->h_unp[2];
     if (derr != 0) {
         switch (derr) {
         case MGS_ERR_MALFORMED: h->err = "the stream does not end at a record boundary"; break;
@@ -1685,9 +1684,14 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
         h->err = fmt("mgs_unpack_device: %llu page cuts, room for %d", (unsigned long long) nc, max_cuts);
         return MGS_ERR_ARG;
     }
+    if (nc > kHeadCuts) {
+        MGS_HIP(h, hipMemcpyAsync(h->h_unp + 4 + 2 * kHeadCuts, p.result + 4 + 2 * kHeadCuts,
+                                  2 * (nc - kHeadCuts) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        MGS_HIP(h, hipStreamSynchronize(stream));
+    }
     for (uint64_t k = 0; k < nc; k++) {
-        cuts[k].first_record = h->h_unp[2 + 2 * k];
-        cuts[k].first_byte = h->h_unp[3 + 2 * k];
+        cuts[k].first_record = h->h_unp[4 + 2 * k];
+        cuts[k].first_byte = h->h_unp[5 + 2 * k];
     }
     *n_cuts = (int) nc;
     return MGS_OK;
@@ -1717,7 +1721,7 @@ int mgs_tokenize_device(mgs_handle *h, const void *d_text, uint64_t nbytes, uint
         return MGS_ERR_HIP;
     }
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
-    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
+    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (4 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
 
     TokParams p;
     memset(&p, 0, sizeof(p));
@@ -1806,7 +1810,7 @@ int mgs_group_device(mgs_handle *h, const void *d_records, const uint32_t *d_rec
         return MGS_ERR_HIP;
     }
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->own_stream;
-    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (2 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
+    if (!h->h_unp) MGS_HIP(h, hipHostMalloc(&h->h_unp, (4 + 2 * kUnpMaxCuts) * sizeof(uint64_t), hipHostMallocDefault));
     *n_groups = 0;
     *n_cuts = 0;
     if (n_records == 0) {

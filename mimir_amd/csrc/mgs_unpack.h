@@ -76,7 +76,7 @@ struct UnpParams {
     int64_t first_fill;
     uint64_t *cuts;       // out: [2*max_cuts] (first_record, first_byte) of every new page
     uint32_t max_cuts;
-    uint64_t *result;     // out: [0] records, [1] number of cuts
+    uint64_t *result;     // out: [0] records, [1] number of cuts, [2] the first status raised (k_unp_pages)
 };
 
 struct __attribute__((packed)) UnpU128 { uint32_t x, y, z, w; };
@@ -662,11 +662,10 @@ __device__ __forceinline__ void unp_pages_walk(const UnpParams &p, int lane)
 __global__ __launch_bounds__(64) void k_unp_pages(UnpParams p)
 {
     if (blockIdx.x != 0) return;
-    if (p.ctrl->head.error != 0) {
-        if (threadIdx.x == 0) p.result[1] = 0;
-        return;
-    }
-    unp_pages_walk(p, threadIdx.x);
+    if (p.ctrl->head.error == 0) unp_pages_walk(p, threadIdx.x);
+    // the call's status travels with its result: one copy back to the host
+    if (threadIdx.x == 0)
+        p.result[2] = (uint64_t) (uint32_t) __hip_atomic_load(&p.ctrl->head.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace mgs

@@ -37,3 +37,7 @@ cat $O/unpack.jsonl | cut -c1-220
 bash $R/tools/prof_unpack.sh r3/unpack_stats > /dev/null 2>&1
 cp $(ls -t $(find $O/unpack_stats -name '*kernel_stats.csv') | head -1) $O/unpack_kernel_stats.csv
 head -5 $O/unpack_kernel_stats.csv
+bash $R/tools/pmc_traffic.sh r3_unpack tools/bench_unpack.py 6e7 2 > $O/traffic_unpack.txt 2>&1 || true
+head -6 $O/traffic_unpack.txt
+bash $R/tools/pmc_sq_tool.sh r3_unpack tools/bench_unpack.py 6e7 2 > $O/unpack_sq_counters.txt 2>&1 || true
+head -40 $O/unpack_sq_counters.txt
