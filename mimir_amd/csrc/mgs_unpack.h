@@ -60,8 +60,9 @@ struct UnpParams {
     uint32_t *table;      // [nchunks][V+2]: exit state << 24 | records, per entry state
     uint8_t *piece_exit;  // [nchunks][64][V+2]
     uint16_t *piece_count; // [nchunks][64][V+2]
-    unsigned long long *masks; // [nchunks][piece_bytes / 64][64]: NUL mask of every 64-byte block of every piece,
-                               // left by k_unp_spec for k_unp_emit (an eighth of the stream, so that it is read once)
+    unsigned long long *masks; // [nchunks][piece_bytes / 128][64][2]: NUL masks of every pair of 64-byte blocks of
+                               // every piece, left by k_unp_spec for k_unp_emit (an eighth of the stream, so
+                               // that it is read once); 16-byte aligned
     uint32_t nruns;       // runs of UNP_RUN chunks
     uint32_t *run_exit;   // [nruns][V+2] exit state of a run per entry state
     uint64_t *run_count;  // [nruns][V+2] records of a run per entry state
@@ -297,7 +298,6 @@ __device__ __forceinline__ void unp_spec_blocks(const UnpParams &p, uint32_t c, 
     for (uint32_t j = 0; j < UNP_AHEAD; j++)
         if (j < ns) unp_rows_load<EDGE>(p, c0, j, lane, ring[j]);
     auto block = [&](uint32_t b, uint64_t nul) {
-        p.masks[((uint64_t) c * nb + b) * 64 + lane] = nul; // one 512-byte row per block: k_unp_emit parses from these
         const uint64_t boff = a0 + 64u * b;
         if (EDGE && boff >= a1) return;
         const uint32_t valid = EDGE ? (uint32_t) min((uint64_t) 64, a1 - boff) : 64u;
@@ -332,6 +332,8 @@ __device__ __forceinline__ void unp_spec_blocks(const UnpParams &p, uint32_t c, 
                 uint64_t nul0, nul1;
                 unp_rows_mask<EDGE>(p, c0, st, lane, ring[j], smask, nul0, nul1);
                 if (st + UNP_AHEAD < ns) unp_rows_load<EDGE>(p, c0, st + UNP_AHEAD, lane, ring[j]); // in flight during the next parses
+                // a lane's two masks side by side, one KiB row per step: k_unp_emit parses from these
+                reinterpret_cast<ulonglong2 *>(p.masks)[((uint64_t) c * ns + st) * 64 + lane] = make_ulonglong2(nul0, nul1);
                 block(2 * st, nul0);
                 block(2 * st + 1, nul1);
             }
@@ -503,10 +505,11 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
     const uint32_t nb = p.piece_bytes / 64;
     // the NUL masks k_unp_spec left (the stream itself is not read again), a few blocks ahead
     constexpr uint32_t AHEAD = 4;
-    const unsigned long long *mrow = p.masks + (uint64_t) c * nb * 64 + lane;
-    unsigned long long mq[AHEAD];
+    const uint32_t ns = nb / 2; // pieces are multiples of 128 bytes: a pair of blocks per step
+    const ulonglong2 *mrow = reinterpret_cast<const ulonglong2 *>(p.masks) + (uint64_t) c * ns * 64 + lane;
+    ulonglong2 mq[AHEAD / 2];
 #pragma unroll
-    for (uint32_t j = 0; j < AHEAD; j++) mq[j] = (j < nb) ? mrow[(uint64_t) j * 64] : 0ull;
+    for (uint32_t j = 0; j < AHEAD / 2; j++) mq[j] = (j < ns) ? mrow[(uint64_t) j * 64] : make_ulonglong2(0ull, 0ull);
     for (uint32_t i = lane; i < UNP_PIECES * S; i += 64)
         stab[i] = ((uint32_t) p.piece_exit[(uint64_t) c * UNP_PIECES * S + i] << 16)
                   | p.piece_count[(uint64_t) c * UNP_PIECES * S + i];
@@ -548,19 +551,23 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
     sink.ring = sink.rings + UNP_SLOT_PITCH * lane;
     sink.out = p.rec_off - back;
     sink.start(first + base + back);
-    for (uint32_t b0 = 0; b0 < nb; b0 += AHEAD) {
+    for (uint32_t s0 = 0; s0 < ns; s0 += AHEAD / 2) {
 #pragma unroll
-        for (uint32_t j = 0; j < AHEAD; j++) {
-            const uint32_t b = b0 + j;
-            const uint64_t nul = mq[j];
-            if (b + AHEAD < nb) mq[j] = mrow[(uint64_t) (b + AHEAD) * 64]; // in flight during the parse
-            const uint64_t boff = a0 + 64u * b;
-            if (b >= nb) continue;
-            if (boff < a1) {
-                const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
-                state = unp_step(nul, state, V, valid, [&](uint32_t pos) { sink.put((uint32_t) boff + pos); });
+        for (uint32_t j = 0; j < AHEAD / 2; j++) {
+            const uint32_t st = s0 + j;
+            const ulonglong2 pair = mq[j];
+            if (st + AHEAD / 2 < ns) mq[j] = mrow[(uint64_t) (st + AHEAD / 2) * 64]; // in flight during the parse
+            if (st >= ns) continue;
+#pragma unroll
+            for (uint32_t hb = 0; hb < 2; hb++) {
+                const uint64_t nul = hb ? pair.y : pair.x;
+                const uint64_t boff = a0 + 64u * (2 * st + hb);
+                if (boff < a1) {
+                    const uint32_t valid = (uint32_t) min((uint64_t) 64, a1 - boff);
+                    state = unp_step(nul, state, V, valid, [&](uint32_t pos) { sink.put((uint32_t) boff + pos); });
+                }
+                sink.store_ready(lane);
             }
-            sink.store_ready(lane);
         }
     }
     sink.finish();
