@@ -1600,7 +1600,8 @@ int mgs_unpack_device(mgs_handle *h, const void *d_stream, uint64_t nbytes, uint
     const uint32_t S = p.V + 2;
     // one wave per chunk, one lane per piece; pieces of at least four 64-byte blocks
     uint64_t chunk = (nbytes + parse_chunks() - 1) / parse_chunks();
-    chunk = std::max<uint64_t>(16384, (chunk + 8191) / 8192 * 8192); // 64 pieces, each a multiple of 128 bytes
+    chunk = (chunk + 16383) / 16384 * 16384; // 64 pieces, each a multiple of 256 bytes (two steps of two blocks)
+    if (chunk == 0) chunk = 16384;
     p.chunk_bytes = (uint32_t) chunk;
     p.piece_bytes = (uint32_t) (chunk / UNP_PIECES);
     p.nchunks = (uint32_t) ((nbytes + chunk - 1) / chunk);

@@ -55,7 +55,7 @@ struct UnpParams {
     uint64_t nbytes;
     uint32_t V;           // bytes to skip after a key's NUL
     uint32_t chunk_bytes; // 64 pieces
-    uint32_t piece_bytes; // multiple of 64, below 65536 (record counts of a piece are 16-bit)
+    uint32_t piece_bytes; // multiple of 128 * UNP_AHEAD, below 65536 (record counts of a piece are 16-bit)
     uint32_t nchunks;
     uint32_t *table;      // [nchunks][V+2]: exit state << 24 | records, per entry state
     uint8_t *piece_exit;  // [nchunks][64][V+2]
@@ -291,12 +291,17 @@ __device__ __forceinline__ void unp_spec_blocks(const UnpParams &p, uint32_t c, 
     const uint64_t a0 = c0 + (uint64_t) lane * p.piece_bytes;
     const uint64_t a1 = min(p.nbytes, a0 + p.piece_bytes); // a1 <= a0: the piece is empty
     const uint32_t nb = p.piece_bytes / 64;
-    // UNP_AHEAD steps of two blocks in flight, each in registers of its own (no moves: a move would wait for its load)
-    const uint32_t ns = nb / 2; // pieces are multiples of 128 bytes
+    // UNP_AHEAD steps of two blocks in flight, each in registers of its own (no moves: a move would wait
+    // for its load).  Every load and store of the loop is issued on every trip -- past the last step the
+    // last step again -- so that the wait for a step's rows can be a count that leaves the younger
+    // requests in flight: with a load under a condition the compiler waits for everything.
+    const uint32_t ns = nb / 2; // a multiple of UNP_AHEAD: pieces are multiples of 128 * UNP_AHEAD bytes
     UnpRows ring[UNP_AHEAD];
 #pragma unroll
-    for (uint32_t j = 0; j < UNP_AHEAD; j++)
-        if (j < ns) unp_rows_load<EDGE>(p, c0, j, lane, ring[j]);
+    for (uint32_t j = 0; j < UNP_AHEAD; j++) {
+        unp_rows_load<EDGE>(p, c0, j, lane, ring[j]);
+        __builtin_amdgcn_sched_barrier(0); // step by step, as the loop requests them: the waits count on the order
+    }
     auto block = [&](uint32_t b, uint64_t nul) {
         const uint64_t boff = a0 + 64u * b;
         if (EDGE && boff >= a1) return;
@@ -328,15 +333,15 @@ __device__ __forceinline__ void unp_spec_blocks(const UnpParams &p, uint32_t c, 
 #pragma unroll
         for (uint32_t j = 0; j < UNP_AHEAD; j++) {
             const uint32_t st = s0 + j;
-            if (st < ns) {
-                uint64_t nul0, nul1;
-                unp_rows_mask<EDGE>(p, c0, st, lane, ring[j], smask, nul0, nul1);
-                if (st + UNP_AHEAD < ns) unp_rows_load<EDGE>(p, c0, st + UNP_AHEAD, lane, ring[j]); // in flight during the next parses
-                // a lane's two masks side by side, one KiB row per step: k_unp_emit parses from these
-                reinterpret_cast<ulonglong2 *>(p.masks)[((uint64_t) c * ns + st) * 64 + lane] = make_ulonglong2(nul0, nul1);
-                block(2 * st, nul0);
-                block(2 * st + 1, nul1);
-            }
+            uint64_t nul0, nul1;
+            unp_rows_mask<EDGE>(p, c0, st, lane, ring[j], smask, nul0, nul1);
+            __builtin_amdgcn_sched_barrier(0);
+            unp_rows_load<EDGE>(p, c0, min(st + UNP_AHEAD, ns - 1), lane, ring[j]); // in flight during the next parses
+            __builtin_amdgcn_sched_barrier(0);
+            // a lane's two masks side by side, one KiB row per step: k_unp_emit parses from these
+            reinterpret_cast<ulonglong2 *>(p.masks)[((uint64_t) c * ns + st) * 64 + lane] = make_ulonglong2(nul0, nul1);
+            block(2 * st, nul0);
+            block(2 * st + 1, nul1);
         }
     }
 }
@@ -505,11 +510,11 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
     const uint32_t nb = p.piece_bytes / 64;
     // the NUL masks k_unp_spec left (the stream itself is not read again), a few blocks ahead
     constexpr uint32_t AHEAD = 4;
-    const uint32_t ns = nb / 2; // pieces are multiples of 128 bytes: a pair of blocks per step
+    const uint32_t ns = nb / 2; // pieces are multiples of 256 bytes: a pair of blocks per step, steps in pairs
     const ulonglong2 *mrow = reinterpret_cast<const ulonglong2 *>(p.masks) + (uint64_t) c * ns * 64 + lane;
     ulonglong2 mq[AHEAD / 2];
 #pragma unroll
-    for (uint32_t j = 0; j < AHEAD / 2; j++) mq[j] = (j < ns) ? mrow[(uint64_t) j * 64] : make_ulonglong2(0ull, 0ull);
+    for (uint32_t j = 0; j < AHEAD / 2; j++) mq[j] = mrow[(uint64_t) j * 64]; // ns is a multiple of AHEAD / 2
     for (uint32_t i = lane; i < UNP_PIECES * S; i += 64)
         stab[i] = ((uint32_t) p.piece_exit[(uint64_t) c * UNP_PIECES * S + i] << 16)
                   | p.piece_count[(uint64_t) c * UNP_PIECES * S + i];
@@ -556,8 +561,7 @@ __global__ __launch_bounds__(64) void k_unp_emit(UnpParams p)
         for (uint32_t j = 0; j < AHEAD / 2; j++) {
             const uint32_t st = s0 + j;
             const ulonglong2 pair = mq[j];
-            if (st + AHEAD / 2 < ns) mq[j] = mrow[(uint64_t) (st + AHEAD / 2) * 64]; // in flight during the parse
-            if (st >= ns) continue;
+            mq[j] = mrow[(uint64_t) min(st + AHEAD / 2, ns - 1) * 64]; // in flight during the parse; issued on every trip
 #pragma unroll
             for (uint32_t hb = 0; hb < 2; hb++) {
                 const uint64_t nul = hb ? pair.y : pair.x;
