@@ -477,15 +477,15 @@ static bool osr_enabled(const mgs_handle *h)
 }
 // Records per lane and register quads for records of about `bytes_per_record` bytes (variable
 // width: 1.25 times the average seen).  The order is the order of preference measured on
-// MI355X: fixed widths above 16 bytes and string keys with few records per lane run fastest
-// with three records per lane and early requests, string keys otherwise with four.
+// MI355X: fixed widths run fastest with early requests and as many records per lane as registers
+// and image take (five of up to 13 bytes, four of up to 32), string keys with four and late requests.
 // (nq = 3 stands for a quad and a dword: records of up to 20 bytes, allowed with q3)
 static bool osr_pick(int lm, bool a4, double bytes_per_record, int shrink, int *k_out, int *nq_out, bool q3 = false)
 {
-    static const int fixed_order[3][2] = {{4, 1}, {3, 2}, {4, 2}};
+    static const int fixed_order[4][2] = {{5, 1}, {4, 1}, {4, 2}, {3, 2}};
     static const int cstr_order[5][2] = {{4, 3}, {4, 2}, {3, 2}, {2, 2}, {1, 2}};
     const int(*cand)[2] = lm == 2 ? fixed_order : cstr_order;
-    const int ncand = lm == 2 ? 3 : 5;
+    const int ncand = lm == 2 ? 4 : 5;
     int skipped = 0;
     for (int i = 0; i < ncand; i++) {
         const int k = cand[i][0], nq = cand[i][1];

@@ -21,9 +21,12 @@ const OsrEntry kOsr[] = {
     // one string key + fixed-width or absent value
     OSR(4, 2, 1, false, false, 0), OSR(3, 2, 1, false, true, 0), OSR(3, 2, 1, false, false, 0), OSR(2, 2, 1, false, true, 0),
     OSR(1, 2, 1, false, true, 0), OSR(4, 3, 1, false, false, 0), OSR(4, 3, 1, false, true, 0),
-    // fixed widths up to 16 / 32 bytes; multiples of four bytes move as dwords
-    OSR(4, 1, 2, false, true, 0), OSR(4, 2, 2, false, false, 0), OSR(3, 2, 2, false, true, 0),
-    OSR(4, 1, 2, true, true, 0), OSR(4, 2, 2, true, false, 0), OSR(3, 2, 2, true, true, 0),
+    // fixed widths up to 16 / 32 bytes; multiples of four bytes move as dwords.  (The early-request form of
+    // a (k, nq) comes first: it is the one a call gets that does not pin PRE.)
+    OSR(5, 1, 2, false, true, 0), OSR(4, 1, 2, false, true, 0), OSR(4, 2, 2, false, true, 0), OSR(4, 2, 2, false, false, 0),
+    OSR(3, 2, 2, false, true, 0),
+    OSR(5, 1, 2, true, true, 0), OSR(4, 1, 2, true, true, 0), OSR(4, 2, 2, true, true, 0), OSR(4, 2, 2, true, false, 0),
+    OSR(3, 2, 2, true, true, 0),
     // diagnostic builds: cycles per phase
     OSR(4, 2, 1, false, false, OSV_STATS), OSR(3, 2, 1, false, true, OSV_STATS), OSR(4, 2, 2, true, false, OSV_STATS),
     OSR(4, 1, 2, true, true, OSV_STATS), OSR(4, 3, 1, false, true, OSV_STATS),
