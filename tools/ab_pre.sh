@@ -1,7 +1,6 @@
 #!/bin/bash
-# Records per lane of k_onesweepr pinned by the environment (a build with extra instantiations and a 72 KB image: libmgs_expk.so).
+# Early / late requests of k_onesweepr pinned by the environment on the string-key shapes (in-tree library).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-export MGS_LIBRARY=$R/mimir_amd/lib/libmgs_expk.so
 run() { local label=$1; shift
   timeout -k 10 200 python $R/bench.py --workload "$@" --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
 import json,sys
@@ -11,8 +10,9 @@ for l in sys.stdin:
 " || echo "failed: $label"
 }
 for rep in 1 2; do
-run "join default (72 KB image)" join
-MGS_OSR_K=5 MGS_OSR_NQ=2 MGS_OSR_PRE=0 run "join K=5 late" join
-run "octree12 default (72 KB image)" octree --level 12
-run "words default" words
+MGS_OSR_PRE=0 run "words late" words
+MGS_OSR_PRE=1 run "words early" words
+MGS_OSR_PRE=0 run "join K=4 late" join
+MGS_OSR_K=3 MGS_OSR_NQ=2 MGS_OSR_PRE=1 run "join K=3 early" join
+MGS_OSR_K=3 MGS_OSR_NQ=2 MGS_OSR_PRE=0 run "join K=3 late" join
 done
