@@ -1,5 +1,5 @@
 #!/bin/bash
-# Records per lane of k_onesweepr pinned by the environment (a build with extra instantiations and a 72 KB image: libmgs_expk.so).
+# Instantiations of k_onesweepr pinned by the environment (a build with extra instantiations: libmgs_expk.so).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export MGS_LIBRARY=$R/mimir_amd/lib/libmgs_expk.so
 run() { local label=$1; shift
@@ -11,8 +11,7 @@ for l in sys.stdin:
 " || echo "failed: $label"
 }
 for rep in 1 2; do
-run "join default (72 KB image)" join
-MGS_OSR_K=5 MGS_OSR_NQ=2 MGS_OSR_PRE=0 run "join K=5 late" join
-run "octree12 default (72 KB image)" octree --level 12
-run "words default" words
+run "octree12 default (4,2,early)" octree --level 12
+MGS_OSR_K=4 MGS_OSR_NQ=3 run "octree12 quad+dword K=4" octree --level 12
+MGS_OSR_K=5 MGS_OSR_NQ=3 run "octree12 quad+dword K=5" octree --level 12
 done
