@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of a build whose k_onesweepr workgroups have 256 threads (libmgs_exphalf.so) on the byte-granular shapes.
+# A/B of a build whose k_onesweepr workgroups have another size (libmgs_exphalf.so: OSR_THREADS, kOvThreads, wg_per_cu and the image sizes changed by hand) on the byte-granular shapes.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for lib in "" $R/mimir_amd/lib/libmgs_exphalf.so "" $R/mimir_amd/lib/libmgs_exphalf.so; do
   echo "== ${lib:-in-tree}"
