@@ -13,10 +13,12 @@ struct OsrEntry {
     int var; // OSV_* bits of the instantiation (0: production)
     OsrKernel fn;
 };
-// NQ: 16-byte register quads per record; 3 stands for a quad and a dword (records up to 20 bytes)
+// NQ: 16-byte register quads per record; 3 stands for a quad and a dword (records up to 20 bytes).
+// The scan wave looks back four rows of tiles per poll for string keys, eight for fixed widths (measured:
+// tools/ab_look.sh; sixteen cost 7 % on every shape).
 #define OSR(K, NQ, LM, A4, PRE, V)                                                                                   \
     {K, NQ, LM, A4, PRE, V,                                                                                          \
-     k_onesweepr<OSR_THREADS, K, (NQ == 3 ? 2 : NQ), V, 4, 8, LM, A4, (NQ == 1 ? OSR_IMG1 : OSR_IMG2), PRE, (NQ == 3 ? 1 : 4)>}
+     k_onesweepr<OSR_THREADS, K, (NQ == 3 ? 2 : NQ), V, 4, (LM == 1 ? 4 : 8), LM, A4, (NQ == 1 ? OSR_IMG1 : OSR_IMG2), PRE, (NQ == 3 ? 1 : 4)>}
 const OsrEntry kOsr[] = {
     // one string key + fixed-width or absent value
     OSR(4, 2, 1, false, false, 0), OSR(3, 2, 1, false, true, 0), OSR(3, 2, 1, false, false, 0), OSR(2, 2, 1, false, true, 0),
